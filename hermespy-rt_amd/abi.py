@@ -1,0 +1,216 @@
+"""ctypes mirror of the reference's C ABI for the compute_paths hot path.
+
+This is the host-side (Python) statement of the drop-in boundary.  Every struct below is
+byte-compatible with the reference header it cites, so the SAME driver code can call
+
+  * the product library  (hermespy-rt_amd/lib/libhermespy_rt_amd.so, HIP path), and
+  * the real reference   (oracle/_ref/libhrt_ref.so, built in place from /root/reference),
+
+which is what lets tests/ run one harness against both.
+
+Reference interface mirrored here:
+  Vec3            inc/vec3.h:6-8
+  Ray             inc/ray.h:6-9
+  Mesh, Scene     inc/scene.h:10-32
+  ChannelInfo     inc/compute_paths.h:13-23
+  RaysInfo        inc/compute_paths.h:26-30
+  compute_paths   inc/compute_paths.h:59-74
+  scene_load      inc/scene.h:105   (returns Scene BY VALUE)
+  scene_save      inc/scene.h:95
+"""
+import ctypes as C
+
+import numpy as np
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("o", Vec3), ("d", Vec3)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("num_vertices", C.c_uint32),
+        ("vs", C.POINTER(Vec3)),
+        ("num_triangles", C.c_uint32),
+        ("is_", C.POINTER(C.c_uint32)),
+        ("material_index", C.c_uint32),
+        ("velocity", Vec3),
+        ("ns", C.POINTER(Vec3)),
+    ]
+
+
+class Scene(C.Structure):
+    _fields_ = [("num_meshes", C.c_uint32), ("meshes", C.POINTER(Mesh))]
+
+
+class ChannelInfo(C.Structure):
+    _fields_ = [
+        ("num_rays", C.c_uint32),
+        ("directions_rx", C.POINTER(Vec3)),
+        ("directions_tx", C.POINTER(Vec3)),
+        ("a_te_re", c_float_p),
+        ("a_te_im", c_float_p),
+        ("a_tm_re", c_float_p),
+        ("a_tm_im", c_float_p),
+        ("tau", c_float_p),
+        ("freq_shift", c_float_p),
+    ]
+
+
+class RaysInfo(C.Structure):
+    _fields_ = [
+        ("num_bounces", C.c_uint32),
+        ("num_rays", C.c_uint32),
+        ("rays", C.POINTER(Ray)),
+        ("rays_active", C.POINTER(C.c_uint8)),
+    ]
+
+
+assert C.sizeof(Vec3) == 12 and C.sizeof(Ray) == 24
+assert C.sizeof(Mesh) == 56 and C.sizeof(Scene) == 16
+assert C.sizeof(ChannelInfo) == 72 and C.sizeof(RaysInfo) == 24
+
+#: bit pattern used to pre-fill every output buffer so "slot not written" is observable
+#: (the reference leaves slots of dead rays untouched).
+SENTINEL_U32 = 0x7FC0DEAD
+
+
+def bind_reference_abi(lib):
+    """Declare argtypes/restype of the three reference entry points on `lib`."""
+    lib.scene_load.argtypes = [C.c_char_p]
+    lib.scene_load.restype = Scene
+    lib.scene_save.argtypes = [C.POINTER(Scene), C.c_char_p]
+    lib.scene_save.restype = None
+    lib.compute_paths.argtypes = [
+        C.POINTER(Scene),
+        C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Vec3),
+        C.c_float,
+        C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+        C.POINTER(ChannelInfo), C.POINTER(RaysInfo),
+        C.POINTER(ChannelInfo), C.POINTER(RaysInfo),
+    ]
+    lib.compute_paths.restype = None
+    return lib
+
+
+def _sentinel(n, dtype=np.float32):
+    if dtype == np.uint8:
+        return np.full(n, 0xAD, dtype=np.uint8)
+    return np.full(n, SENTINEL_U32, dtype=np.uint32).view(np.float32)
+
+
+def _vec3_arg(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(n, 3))
+    return a, a.ctypes.data_as(C.POINTER(Vec3))
+
+
+def free_scene(scene):
+    """inc/scene.h:72-86 (static inline in the reference header; uses free())."""
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for i in range(scene.num_meshes):
+        m = scene.meshes[i]
+        for p in (m.vs, m.is_, m.ns):
+            libc.free(C.cast(p, C.c_void_p))
+    libc.free(C.cast(scene.meshes, C.c_void_p))
+
+
+def scene_to_numpy(scene):
+    """Deep-copy a loaded Scene into python lists of numpy arrays (for inspection/tests)."""
+    out = []
+    for i in range(scene.num_meshes):
+        m = scene.meshes[i]
+        vs = np.ctypeslib.as_array(C.cast(m.vs, c_float_p), shape=(m.num_vertices, 3)).copy()
+        idx = np.ctypeslib.as_array(m.is_, shape=(m.num_triangles, 3)).copy()
+        ns = None
+        if m.ns:
+            ns = np.ctypeslib.as_array(C.cast(m.ns, c_float_p), shape=(m.num_triangles, 3)).copy()
+        out.append(dict(vs=vs, idx=idx, material_index=int(m.material_index),
+                        velocity=np.array([m.velocity.x, m.velocity.y, m.velocity.z], np.float32),
+                        ns=ns))
+    return out
+
+
+def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
+                      num_bounces, zero_freq_shift=None, with_rays=True):
+    """Call `lib.compute_paths` the way the reference's own callers do
+    (compute_paths_pybind11.cpp:99-186, test/test.c:10-75) and return every output as numpy.
+
+    All outputs are pre-filled with SENTINEL_U32 so unwritten slots are visible.  The scatter
+    freq_shift is zero-filled when num_tx > 1 (the reference memcpy-replicates caller memory
+    there) unless `zero_freq_shift` overrides.  rays_active is allocated with
+    the size the callee really needs, (ntx*nb+1)*(np/8+1).
+    """
+    rx_pos = np.asarray(rx_pos, np.float32).reshape(-1, 3)
+    tx_pos = np.asarray(tx_pos, np.float32).reshape(-1, 3)
+    nrx, ntx = rx_pos.shape[0], tx_pos.shape[0]
+    npth, nb = int(num_paths), int(num_bounces)
+    rxp, rxp_c = _vec3_arg(rx_pos, nrx)
+    txp, txp_c = _vec3_arg(tx_pos, ntx)
+    rxv, rxv_c = _vec3_arg(rx_vel, nrx)
+    txv, txv_c = _vec3_arg(tx_vel, ntx)
+
+    def chan(n, n_dir_tx):
+        d = dict(directions_rx=_sentinel(3 * n), directions_tx=_sentinel(3 * n_dir_tx),
+                 a_te_re=_sentinel(n), a_te_im=_sentinel(n), a_tm_re=_sentinel(n),
+                 a_tm_im=_sentinel(n), tau=_sentinel(n), freq_shift=_sentinel(n))
+        ci = ChannelInfo()
+        for k, v in d.items():
+            ptr_t = C.POINTER(Vec3) if k.startswith("directions") else c_float_p
+            setattr(ci, k, v.ctypes.data_as(ptr_t))
+        return d, ci
+
+    n_los = nrx * ntx
+    n_scat = nrx * ntx * nb * npth
+    los, los_c = chan(n_los, n_los)
+    scat, scat_c = chan(n_scat, n_scat)
+    los_c.num_rays = 1
+    scat_c.num_rays = (nb * npth) & 0xFFFFFFFF
+    if zero_freq_shift is None:
+        zero_freq_shift = ntx > 1
+    if zero_freq_shift:
+        scat["freq_shift"][:] = 0.0
+
+    los_rays = _sentinel(6 * n_los)
+    los_active = _sentinel(n_los // 8 + 1, np.uint8)
+    n_rays_scat = ntx * (nb + 1) * npth
+    n_act_scat = (ntx * nb + 1) * (npth // 8 + 1)
+    scat_rays = _sentinel(6 * n_rays_scat)
+    scat_active = _sentinel(n_act_scat, np.uint8)
+    lr = RaysInfo(1, 1, los_rays.ctypes.data_as(C.POINTER(Ray)),
+                  los_active.ctypes.data_as(C.POINTER(C.c_uint8)))
+    sr = RaysInfo(nb + 1, npth & 0xFFFFFFFF, scat_rays.ctypes.data_as(C.POINTER(Ray)),
+                  scat_active.ctypes.data_as(C.POINTER(C.c_uint8)))
+
+    scene = lib.scene_load(str(scene_path).encode())
+    try:
+        lib.compute_paths(C.byref(scene), rxp_c, txp_c, rxv_c, txv_c, C.c_float(f_ghz),
+                          nrx, ntx, npth, nb,
+                          C.byref(los_c), C.byref(lr) if with_rays else C.byref(lr),
+                          C.byref(scat_c), C.byref(sr))
+        normals = [m["ns"] for m in scene_to_numpy(scene)]
+    finally:
+        free_scene(scene)
+
+    shp = (nrx, ntx, nb, npth)
+    res = dict(
+        los={k: (v.reshape(nrx, ntx, 3) if k.startswith("directions") else v.reshape(nrx, ntx))
+             for k, v in los.items()},
+        scat={k: (v.reshape(*shp, 3) if k.startswith("directions") else v.reshape(shp))
+              for k, v in scat.items()},
+        los_rays=los_rays.reshape(n_los, 6), los_active=los_active,
+        scat_rays=scat_rays.reshape(n_rays_scat, 6), scat_active=scat_active,
+        normals=normals,
+    )
+    return res
+
+
+def written(a):
+    """Boolean mask of slots whose bit pattern is not the sentinel."""
+    return a.view(np.uint32) != SENTINEL_U32
