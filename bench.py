@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- the compute_paths hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the whole launch set of the workload: state init
+from the (HBM-resident) launch directions, LoS pass, num_bounces+1 launches of the bounce
+kernel (trace + Fresnel + reflect + compaction + scatter-to-RX records), and -- for N > 1 --
+the RCCL gather of every rank's compact path records to rank 0.  Inputs (scene, endpoints,
+launch directions) are resident in HBM before the timed region; outputs stay in HBM.
+
+Workload at N = 1 is BASELINE.json configs[2] (the config its metric and target are quoted
+on): simple_street_canyon_with_cars.hrt, 1 TX + 4 RX, 4M rays, 4 bounces, 3.5 GHz, endpoints
+as fixed in SURVEY.md 8(d).  Scaling is WEAK: N GPUs trace an N-times denser Fibonacci
+sphere (N x 4M rays), ray-sharded round-robin in 4096-path granules.
+
+Prints ONE JSON line on rank 0.  metric = resolved propagation paths per second (scatter
+records written, blocked ones included, + LoS entries), whole job; ray-triangle tests/s of
+the brute-force algorithm is reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def workloads():
+    from tests import configs as K
+    return {"c1": K.C1, "c2": K.C2, "c3": K.C3, "c4": K.C4, "c5": K.C5,
+            "c3_doppler": K.C3_DOPPLER}
+
+
+def describe(c):
+    return "%s, %d TX + %d RX, %d rays/TX, %d bounces, %.1f GHz" % (
+        os.path.basename(c["scene_path"]), len(c["tx_pos"]), len(c["rx_pos"]), c["num_paths"],
+        c["num_bounces"], c["f_ghz"])
+
+
+def algorithmic_bytes(live, nrx, n_launch_rays, rec_unblocked, rec_blocked):
+    """B = sum_b (44 A_b + 44 H_b) + 12 np + 36 R_unblocked + 20 R_blocked.
+    44 = Ray 24 + gains 16 + tau 4; a record is 36 B (4 gains, tau, dir_rx, freq_shift),
+    a blocked record 20 B."""
+    nb = len(live) - 1
+    b = 0
+    for k in range(nb):
+        b += 44 * live[k] + 44 * live[k + 1]
+    return b + 12 * n_launch_rays + 36 * rec_unblocked + 20 * rec_blocked
+
+
+def cpu_baseline(c, budget_s=20.0):
+    """The reference itself (oracle/_ref, built in place from the reference sources; it is
+    single-threaded) on a bounded sample of the workload, else our CPU port of it."""
+    import ctypes
+    from oracle import oracle
+    out = {}
+    ref_so = os.path.join(REPO, "oracle", "_ref", "libhrt_ref.so")
+    # single-thread reference does ~1.2e8 tests/s on C3; size the sample for
+    # about budget_s: a sparser Fibonacci sphere of the same scene/endpoints
+    T = len(oracle.flatten(oracle.read_hrt(c["scene_path"]))["tri_vtx"])
+    per_ray = T * (1 + len(c["rx_pos"])) * c["num_bounces"] * len(c["tx_pos"]) * 0.5
+    n_sample = int(min(c["num_paths"], max(10000, budget_s * 1.0e8 / max(per_ray, 1.0))))
+    sc = dict(c, num_paths=n_sample)
+    from tests import configs as K
+    if os.path.exists(ref_so):
+        from hermespy_rt_amd import abi
+        lib = abi.bind_reference_abi(ctypes.CDLL(ref_so))
+        t0 = time.time()
+        r = abi.run_compute_paths(lib, *K.args(sc))
+        dt = time.time() - t0
+        recs = int(abi.written(r["scat"]["a_te_re"]).sum()) + len(c["rx_pos"]) * len(c["tx_pos"])
+        out = dict(value=recs / dt, unit="paths/s", cores=1, kind="reference",
+                   sample="%s (num_paths %d of %d), reference src/compute_paths.c built "
+                          "gcc -O3 -ffp-contract=off, %.1f s" % (describe(sc), n_sample, c["num_paths"], dt))
+        del r
+    # our port, all host cores (an upper bound for an embarrassingly parallel CPU version)
+    # the box's CPU share for one GPU is 16 threads
+    nthr = min(16, oracle.lib().hrt_oracle_max_threads(), len(os.sched_getaffinity(0)))
+    t0 = time.time()
+    o = oracle.compute_paths(*K.args(sc), num_threads=nthr)
+    dt = time.time() - t0
+    recs = int(o["extras"]["live"][1:].sum()) * len(c["rx_pos"]) + len(c["rx_pos"]) * len(c["tx_pos"])
+    port = dict(value=recs / dt, unit="paths/s", cores=nthr, kind="port",
+                tests_per_s=o["extras"]["tests"] / dt,
+                sample="%s (num_paths %d of %d), oracle/hrt_oracle.c OpenMP, %.1f s" % (
+                    describe(sc), n_sample, c["num_paths"], dt))
+    if out:
+        out["tests_per_s"] = o["extras"]["tests"] / max(1e-9, float(out["sample"].split(",")[-1].split()[0]))
+        out["port_all_cores"] = port
+        return out
+    return port
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hermespy_rt_amd.device import Tracer
+    from hermespy_rt_amd import sharding
+
+    base = workloads()[args.workload]
+    c = dict(base, num_paths=base["num_paths"] * world)   # weak scaling: denser sphere
+    tr = Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"], c["f_ghz"],
+                c["num_paths"], c["num_bounces"], rank=rank, world=world)
+    gather = sharding.RecordGather(tr) if (world > 1 and not args.no_gather) else None
+
+    def step(timed):
+        t = tr.trace(timed=timed)
+        if gather is not None:
+            gather.run()
+        return t
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    bounce_ms, los_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lm, bm = step(True)   # HIP events around every launch, on the launch stream
+        los_ms.append(lm)
+        bounce_ms.append(bm)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    dt = float(t_all.item())
+
+    # ---- work done (identical every step) ----
+    counts = tr.counts()
+    w = tr.work(counts)
+    nrx, ntx, nb = tr.nrx, tr.ntx, tr.nb
+    unblocked = 0
+    for b in range(nb):
+        n = int(counts[b + 1])
+        if n:
+            unblocked += int(tr.records(b, n)["unblocked"].sum().item())
+    local = torch.tensor([w["records"], w["tests"] - nrx * ntx * tr.num_tri, unblocked] + w["live"],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+    tot = [int(x) for x in local.tolist()]
+    records, tests, unblk, live = tot[0], tot[1] + nrx * ntx * tr.num_tri, tot[2], tot[3:]
+    paths = records + nrx * ntx
+
+    # ---- roofline of the dominant kernel (hrt_bounce_kernel), rank 0's launches ----
+    bm = np.asarray(bounce_ms, dtype=np.float64)          # [steps, nb+1]
+    kern_ms_step = float(bm.sum(axis=1).mean())
+    n_launch = bm.shape[1]
+    unb_local = unblocked
+    B_local = algorithmic_bytes(w["live"], nrx, tr.num_local, unb_local, w["records"] - unb_local)
+    ach = B_local / (kern_ms_step * 1e-3) / 1e9
+    tests_local = w["tests"]
+    roofline = dict(bound="hbm", kernel="hrt_bounce_kernel", achieved=ach, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    algorithmic_bytes_per_launch=B_local / n_launch,
+                    avg_launch_ms=kern_ms_step / n_launch, launches_per_step=n_launch,
+                    per_launch_ms=[float(x) for x in bm.mean(axis=0)],
+                    kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
+                    note="VALU-bound brute-force intersection: see DESIGN.md (valu fraction)")
+
+    if rank == 0:
+        out = dict(
+            metric="resolved propagation paths/sec", value=paths * args.steps / dt,
+            unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload=describe(c), name=args.workload,
+                        parallelism="ray-sharded x%d, round-robin 4096-path granules%s" % (
+                            world, "" if gather is None else ", RCCL gather to rank 0"),
+                        rays_total=c["num_paths"] * ntx),
+            ray_tri_tests_per_sec=tests * args.steps / dt,
+            nonzero_paths_per_sec=(unblk + nrx * ntx) * args.steps / dt,
+            work=dict(live=live, records=records, records_unblocked=unblk, tests=tests),
+            roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

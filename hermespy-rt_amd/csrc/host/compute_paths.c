@@ -1,0 +1,363 @@
+/* compute_paths.c -- the drop-in entry point: host arrays in, the reference's dense layout out.
+ *
+ * Replaces src/compute_paths.c:419-757 of the reference behind the same C symbol
+ * (inc/compute_paths.h:59-74).  The tracing itself happens on the GPU (hrt_trace); this file
+ * only moves data and lays the compact device result out the way the reference's callers
+ * expect, INCLUDING the reference's observable layout quirks:
+ *   Q1  scatter directions_tx is never written
+ *   Q2  slots of dead rays, and directions/freq_shift of blocked records, are not touched
+ *   Q3  a blocked LoS pair leaves its directions/freq_shift untouched
+ *   Q9  scatter freq_shift launch term + memcpy replication (src/compute_paths.c:494-508)
+ *   Q10 the "+= 0" on freq_shift[tx*np+path] (:663-664); replayed for num_tx == 1, where the
+ *       slot belongs to the same ray (for num_tx > 1 it only ever adds an exact zero to
+ *       another ray's slot and is skipped)
+ *   Q11/Q12/Q14 RaysInfo snapshot offsets use stride num_bounces, the active-mask snapshot is
+ *       always taken from byte 0, dead rays keep their last origin/direction
+ *
+ * Rays are processed in batches (round-robin shards of the path index, hrt_device.h) sized to
+ * a device-memory budget, so the dense ABI works for any num_rays the HOST arrays can hold
+ * (with raysInfo_scat != NULL the launch set must fit one batch).
+ *
+ * There is no CPU tracing path here: any HIP failure is an error.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hrt_internal.h"
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static uint64_t env_u64(const char *name, uint64_t dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? strtoull(v, NULL, 10) : dflt;
+}
+
+typedef struct {
+    void *d_dirs, *d_ws;
+    float *h_dirs;          /* launch directions of the whole sphere, [np][3] */
+    uint32_t *h_counts;
+    float *h_los;
+    uint32_t *ray, *tri;    /* per-bounce downloads */
+    float *st[6];           /* o, d of the hits */
+    float *rec[HRT_REC_FIELDS];
+    uint64_t *mask;
+    Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
+    uint8_t *active, *next_active;
+    float *dirs_batch;      /* gathered launch directions of one batch */
+    int device;
+} work_t;
+
+static void work_free(work_t *w)
+{
+    if (w->d_dirs) hrt_device_free(w->device, w->d_dirs);
+    if (w->d_ws) hrt_device_free(w->device, w->d_ws);
+    free(w->h_dirs); free(w->h_counts); free(w->h_los); free(w->ray); free(w->tri);
+    for (int k = 0; k < 6; ++k) free(w->st[k]);
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) free(w->rec[k]);
+    free(w->dirs_batch); free(w->mask); free(w->cur_rays); free(w->active); free(w->next_active);
+}
+
+#define DL(dst, off, bytes)                                                              \
+    do {                                                                                 \
+        rc = hrt_device_download(w.device, (dst), (const uint8_t *)w.d_ws + (off), (bytes)); \
+        if (rc) goto done;                                                               \
+    } while (0)
+
+int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                         const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t nrx,
+                         size_t ntx, size_t np, size_t nb, ChannelInfo *los, RaysInfo *los_rays,
+                         ChannelInfo *scat, RaysInfo *scat_rays, hrt_stats *stats)
+{
+    const double t_begin = hrt_now_s();
+    if (!scene || !los || !scat) return hrt_fail(HRT_E_INVALID, "compute_paths: NULL argument");
+    if (np == 0 || nb == 0) return hrt_fail(HRT_E_INVALID, "num_rays and num_bounces must be > 0");
+    if (nb > 32) return hrt_fail(HRT_E_INVALID, "num_bounces > 32 is not supported");
+
+    hrt_stats st;
+    memset(&st, 0, sizeof st);
+    work_t w;
+    memset(&w, 0, sizeof w);
+    w.device = env_int("HRT_DEVICE", 0);
+    st.device = w.device;
+    hrt_problem *prob = NULL;
+    int rc = hrt_problem_create(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, w.device,
+                                &prob);
+    if (rc) return rc;
+    const uint32_t T = prob->num_tri;
+    const size_t nq = ntx * np;
+
+    /* normals: the reference leaves them in the scene for the caller (:208-224) */
+    {
+        uint32_t j = 0;
+        for (uint32_t i = 0; i < scene->num_meshes; ++i) {
+            Mesh *m = &scene->meshes[i];
+            free(m->ns);
+            m->ns = (Vec3 *)malloc((size_t)(m->num_triangles ? m->num_triangles : 1) * sizeof(Vec3));
+            if (!m->ns) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            for (uint32_t f = 0; f < m->num_triangles; ++f, ++j)
+                memcpy(&m->ns[f], prob->h_tri + (size_t)j * HRT_TRI_FLOATS + 9, sizeof(Vec3));
+        }
+    }
+    st.t_setup_s = hrt_now_s() - t_begin;
+
+    /* ---- launch directions of the whole sphere (host libm, threads) ---- */
+    double t0 = hrt_now_s();
+    hrt_shard whole = {np, 0, 1, 0, (uint32_t)nb};
+    w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
+    if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+    rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
+    if (rc) goto done;
+    st.t_launch_dirs_s = hrt_now_s() - t0;
+
+    /* ---- dense pre-fills that do not depend on the trace ---- */
+    /* Q9, literally: launch term at [tx*np*nb + p], then the two memcpy replications */
+    for (size_t tx = 0; tx < ntx; ++tx)
+        for (size_t p = 0; p < np; ++p) {
+            const float *d = w.h_dirs + 3 * p;
+            float v = tx_vel[tx].x * d[0] + tx_vel[tx].y * d[1] + tx_vel[tx].z * d[2];
+            scat->freq_shift[tx * np * nb + p] = v * prob->dop_mult;
+        }
+    for (size_t b = 1; b < nb; ++b)
+        memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
+    for (size_t rx = 1; rx < nrx; ++rx)
+        memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
+
+    if (scat_rays) {
+        /* :469-471 and :589 */
+        for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
+        w.cur_rays = (Ray *)malloc(nq * sizeof(Ray));
+        w.active = (uint8_t *)malloc(nq / 8 + 1);
+        w.next_active = (uint8_t *)malloc(nq / 8 + 1);
+        if (!w.cur_rays || !w.active || !w.next_active) {
+            rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
+            goto done;
+        }
+        memset(w.active, 0xff, nq / 8 + 1);
+        for (size_t tx = 0; tx < ntx; ++tx)
+            for (size_t p = 0; p < np; ++p) {
+                Ray *r = &w.cur_rays[tx * np + p];
+                r->o = tx_pos[tx];
+                memcpy(&r->d, w.h_dirs + 3 * p, sizeof(Vec3));
+            }
+        memcpy(scat_rays->rays, w.cur_rays, nq * sizeof(Ray));
+    }
+
+    /* ---- batches: how many round-robin shards so one workspace fits the budget ---- */
+    uint64_t free_b = 0, total_b = 0;
+    rc = hrt_device_mem_info(w.device, &free_b, &total_b);
+    if (rc) goto done;
+    uint64_t budget = env_u64("HRT_WORKSPACE_BYTES", 0);
+    if (!budget) {
+        budget = free_b / 2;
+        if (budget > (16ull << 30)) budget = 16ull << 30;
+    }
+    uint32_t G = 1;
+    hrt_layout L;
+    /* RaysInfo snapshots copy the state of EVERY ray after each bounce, so that output needs
+     * the whole launch set in one batch; without it the batches are independent. */
+    for (; !scat_rays;) {
+        hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
+        rc = hrt_layout_query(prob, &s, &L);
+        if (rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 12 <= budget) break;
+        if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
+        if ((uint64_t)G * 4096 >= np) {   /* one granule per batch and still too big */
+            if (rc == HRT_OK) break;      /* try anyway; hipMalloc decides */
+            goto done;
+        }
+        G *= 2;
+    }
+    {
+        hrt_shard s0 = {np, 0, G, 0, (uint32_t)nb};
+        rc = hrt_layout_query(prob, &s0, &L);   /* rank 0 is never smaller than the others */
+        if (rc) goto done;
+        const uint64_t n_loc_max = hrt_shard_num_local(&s0);
+        const uint64_t cap = L.cap;
+        if ((rc = hrt_device_malloc(w.device, &w.d_ws, L.total_bytes))) goto done;
+        if ((rc = hrt_device_malloc(w.device, &w.d_dirs, n_loc_max * 12))) goto done;
+        w.h_counts = (uint32_t *)calloc(nb + 2, 4);
+        w.h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+        w.ray = (uint32_t *)malloc(cap * 4);
+        w.tri = (uint32_t *)malloc(cap * 4);
+        w.mask = (uint64_t *)malloc(cap / 64 * 8);
+        int ok = w.h_counts && w.h_los && w.ray && w.tri && w.mask;
+        for (int k = 0; k < 6 && scat_rays; ++k) ok &= (w.st[k] = (float *)malloc(cap * 4)) != NULL;
+        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= (w.rec[k] = (float *)malloc(cap * 4)) != NULL;
+        if (!ok) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+    }
+
+    double t_dev = 0.0, t_rb = 0.0;
+
+    for (uint32_t g = 0; g < G; ++g) {
+        hrt_shard s = {np, g, G, 0, (uint32_t)nb};
+        const uint64_t n_loc = hrt_shard_num_local(&s);
+        if (n_loc == 0) continue;
+        rc = hrt_layout_query(prob, &s, &L);
+        if (rc) goto done;
+        /* this batch's launch directions: gather from the whole-sphere table */
+        const float *src = w.h_dirs;
+        if (G > 1) {
+            if (!w.dirs_batch) w.dirs_batch = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
+            if (!w.dirs_batch) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            for (uint64_t i = 0; i < n_loc; ++i)
+                memcpy(w.dirs_batch + 3 * i, w.h_dirs + 3 * hrt_shard_global_path(&s, i), 12);
+            src = w.dirs_batch;
+        }
+        t0 = hrt_now_s();
+        if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;
+        if ((rc = hrt_trace(prob, &s, (const float *)w.d_dirs, w.d_ws, L.total_bytes, NULL, NULL))) goto done;
+        if ((rc = hrt_device_sync(w.device, NULL))) goto done;
+        t_dev += hrt_now_s() - t0;
+
+        t0 = hrt_now_s();
+        DL(w.h_counts, L.off_counts, (nb + 2) * 4);
+        {
+            hrt_stats bs;
+            hrt_work_from_counts(prob, &s, w.h_counts, &bs);
+            for (size_t b = 0; b <= nb; ++b) st.live[b] += bs.live[b];
+            st.records += bs.records;
+            st.tests += bs.tests - (g ? (uint64_t)nrx * ntx * T : 0);   /* LoS counted once */
+        }
+
+        /* ---- LoS block (identical in every batch; written once) :515-577 ---- */
+        if (g == 0) {
+            DL(w.h_los, L.off_los, nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+            for (size_t off = 0; off < nrx * ntx; ++off) los->a_te_im[off] = los->a_tm_im[off] = 0.f;
+            for (size_t rx = 0, off = 0; rx < nrx; ++rx)
+                for (size_t tx = 0; tx < ntx; ++tx, ++off) {
+                    const float *q = w.h_los + HRT_LOS_FLOATS * off;
+                    uint32_t status;
+                    memcpy(&status, &q[HRT_LOS_STATUS], 4);
+                    const uint8_t bit = (uint8_t)(1u << (off % 8));
+                    if (los_rays) {
+                        Ray *r = &los_rays->rays[off];
+                        r->o = tx_pos[tx];
+                        r->d.x = rx_pos[rx].x - tx_pos[tx].x;
+                        r->d.y = rx_pos[rx].y - tx_pos[tx].y;
+                        r->d.z = rx_pos[rx].z - tx_pos[tx].z;
+                    }
+                    if (status == 0u) {          /* coincident */
+                        los->directions_rx[off] = (Vec3){1.f, 0.f, 0.f};
+                        los->directions_tx[off] = (Vec3){-1.f, 0.f, 0.f};
+                        los->a_te_re[off] = los->a_tm_re[off] = 1.f;
+                        los->tau[off] = 0.f;
+                        los->freq_shift[off] = 0.f;
+                        if (los_rays) los_rays->rays_active[off / 8] |= bit;
+                    } else if (status == 1u) {   /* blocked: Q3 */
+                        los->a_te_re[off] = los->a_tm_re[off] = los->tau[off] = 0.f;
+                        if (los_rays) los_rays->rays_active[off / 8] &= (uint8_t)~bit;
+                    } else {
+                        Vec3 u = {q[HRT_LOS_DIRX], q[HRT_LOS_DIRY], q[HRT_LOS_DIRZ]};
+                        los->directions_tx[off] = u;
+                        los->directions_rx[off] = (Vec3){-u.x, -u.y, -u.z};
+                        los->a_te_re[off] = los->a_tm_re[off] = q[HRT_LOS_A];
+                        los->tau[off] = q[HRT_LOS_TAU];
+                        los->freq_shift[off] = q[HRT_LOS_FS];
+                        if (los_rays) los_rays->rays_active[off / 8] |= bit;
+                    }
+                }
+        }
+
+        /* ---- bounces: scatter the compact blocks into the dense arrays ---- */
+        for (size_t b = 0; b < nb; ++b) {
+            const uint64_t H = w.h_counts[b + 1];
+            const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
+            if (H) {
+                DL(w.ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
+                DL(w.tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
+                if (scat_rays)
+                    for (int k = 0; k < 6; ++k)
+                        DL(w.st[k], hb + (uint64_t)(HRT_HIT_OX + k) * L.cap * 4, H * 4);
+            }
+            /* Q10 (num_tx == 1 only): fs[p] += dot(d - d, mesh_velocity) * f/c, before the
+             * records of this ray are applied */
+            if (ntx == 1)
+                for (uint64_t i = 0; i < H; ++i) {
+                    const uint64_t p = hrt_shard_global_path(&s, w.ray[i]);
+                    const float *mv = prob->h_mesh + (size_t)prob->h_tri_mesh[w.tri[i]] * HRT_MESH_FLOATS;
+                    const float zero = 0.f;   /* d - d with finite d */
+                    float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
+                    scat->freq_shift[p] += z * prob->dop_mult;
+                }
+            for (size_t rx = 0; rx < nrx && H; ++rx) {
+                const uint64_t rb = L.off_recs + b * L.rec_block_bytes + (uint64_t)rx * HRT_REC_FIELDS * L.cap * 4;
+                for (int k = 0; k < HRT_REC_FIELDS; ++k) DL(w.rec[k], rb + (uint64_t)k * L.cap * 4, H * 4);
+                DL(w.mask, L.off_masks + ((uint64_t)b * nrx + rx) * (L.cap / 64) * 8, (H + 63) / 64 * 8);
+                for (uint64_t i = 0; i < H; ++i) {
+                    const uint32_t ql = w.ray[i];
+                    const uint64_t n_loc32 = n_loc;
+                    const size_t tx = ql / n_loc32;
+                    const uint64_t p = hrt_shard_global_path(&s, ql - tx * n_loc32);
+                    const size_t off = ((rx * ntx + tx) * nb + b) * np + p;   /* :674 */
+                    scat->a_te_re[off] = w.rec[HRT_REC_A_TE_RE][i];
+                    scat->a_te_im[off] = w.rec[HRT_REC_A_TE_IM][i];
+                    scat->a_tm_re[off] = w.rec[HRT_REC_A_TM_RE][i];
+                    scat->a_tm_im[off] = w.rec[HRT_REC_A_TM_IM][i];
+                    scat->tau[off] = w.rec[HRT_REC_TAU][i];
+                    if ((w.mask[i >> 6] >> (i & 63)) & 1u) {
+                        scat->directions_rx[off] = (Vec3){w.rec[HRT_REC_DIRX][i], w.rec[HRT_REC_DIRY][i], w.rec[HRT_REC_DIRZ][i]};
+                        scat->freq_shift[off] -= w.rec[HRT_REC_DFS][i];       /* :722 */
+                        ++st.records_unblocked;
+                    }
+                }
+            }
+
+            /* ---- RaysInfo snapshots (:732-743) ---- */
+            if (scat_rays && G == 1) {
+                memset(w.next_active, 0, nq / 8);           /* bits >= nq keep their ones */
+                w.next_active[nq / 8] = w.active[nq / 8];
+                for (size_t q = nq - nq % 8; q < nq; ++q) w.next_active[q / 8] &= (uint8_t)~(1u << (q % 8));
+                for (uint64_t i = 0; i < H; ++i) {
+                    const uint32_t q = w.ray[i];            /* one batch: local id == tx*np+p */
+                    w.next_active[q / 8] |= (uint8_t)(1u << (q % 8));
+                    Ray *r = &w.cur_rays[q];
+                    r->o = (Vec3){w.st[0][i], w.st[1][i], w.st[2][i]};
+                    r->d = (Vec3){w.st[3][i], w.st[4][i], w.st[5][i]};
+                }
+                const size_t nbytes = np / 8 + 1;
+                for (size_t tx = 0; tx < ntx; ++tx) {
+                    const size_t off_rays = (tx * nb + (b + 1)) * np;
+                    const size_t off_act = (tx * nb + (b + 1)) * nbytes;
+                    memcpy(scat_rays->rays + off_rays, w.cur_rays + tx * np, np * sizeof(Ray));
+                    uint8_t *dst = scat_rays->rays_active + off_act;
+                    memcpy(dst, w.next_active, nbytes);
+                    if (tx == 0 && ntx > 1)   /* Q12: tx1's first bits are still last bounce's */
+                        for (size_t bitp = np; bitp < 8 * nbytes; ++bitp) {
+                            uint8_t m = (uint8_t)(1u << (bitp % 8));
+                            dst[bitp / 8] = (uint8_t)((dst[bitp / 8] & ~m) | (w.active[bitp / 8] & m));
+                        }
+                }
+                uint8_t *sw = w.active; w.active = w.next_active; w.next_active = sw;
+            }
+        }
+        t_rb += hrt_now_s() - t0;
+    }
+
+    st.t_device_s = t_dev;
+    st.t_readback_s = t_rb;
+    st.t_total_s = hrt_now_s() - t_begin;
+    if (stats) *stats = st;
+    rc = HRT_OK;
+
+done:
+    work_free(&w);
+    hrt_problem_destroy(prob);
+    return rc;
+}
+
+void compute_paths(Scene *scene, Vec3 *rx_pos, Vec3 *tx_pos, Vec3 *rx_vel, Vec3 *tx_vel,
+                   float f_ghz, size_t nrx, size_t ntx, size_t np, size_t nb,
+                   ChannelInfo *los, RaysInfo *los_rays, ChannelInfo *scat, RaysInfo *scat_rays)
+{
+    int rc = hrt_compute_paths_ex(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, np, nb,
+                                  los, los_rays, scat, scat_rays, NULL);
+    if (rc != HRT_OK) {
+        fprintf(stderr, "hermespy-rt_amd: compute_paths failed (%d): %s\n", rc, hrt_last_error());
+        exit(70);
+    }
+}

@@ -1,0 +1,59 @@
+/* hrt_internal.h -- shared declarations of the host C part of libhermespy_rt_amd. */
+#ifndef HRT_INTERNAL_H
+#define HRT_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hermespy_rt.h"
+#include "hrt_device.h"
+#include "../hrt_kparams.h"
+
+/* src/compute_paths.c:18-19 of the reference: both are FLOAT constants there */
+#define HRT_PI_F 3.14159265358979323846f
+#define HRT_C_F 299792458.0f
+
+/* ITU-R P.2040-3 material parameters (materials.c) */
+typedef struct {
+    float a, b, c, d;   /* eta' = a f^b, sigma = c f^d (f in GHz) */
+    float s;            /* scattering coefficient */
+    uint8_t s1_alpha;   /* directive lobe width */
+} hrt_material;
+extern const hrt_material hrt_materials[HRT_NUM_MATERIALS];
+
+/* src/compute_paths.c:125-132 field order */
+typedef struct {
+    float eta_re, eta_sqrt_re, eta_inv_re, eta_inv_sqrt_re;
+    float eta_im, eta_sqrt_im, eta_inv_im, eta_inv_sqrt_im;
+    float eta_abs, eta_abs_pow2, eta_abs_inv_sqrt;
+    float r;
+} hrt_eta;
+void hrt_material_eta(uint32_t material_index, float f_ghz, hrt_eta *out);
+
+struct hrt_problem {
+    int device;
+    uint32_t num_tri, num_mesh, num_rx, num_tx;
+    float f_ghz, fsl_mult, dop_mult;
+    /* host copies */
+    float *h_tri;       /* [num_tri][HRT_TRI_FLOATS] */
+    float *h_mesh;      /* [num_mesh][HRT_MESH_FLOATS] */
+    float *h_mat;       /* [17][HRT_MAT_FLOATS] */
+    uint32_t *h_tri_mesh, *h_tri_face;
+    hrt_eta eta[HRT_NUM_MATERIALS];
+    /* one device allocation holding everything */
+    void *d_blob;
+    const float *d_tri, *d_mesh, *d_mat, *d_rx_pos, *d_tx_pos, *d_rx_vel, *d_tx_vel;
+};
+
+/* error plumbing: set the thread's last-error text and return `code` */
+int hrt_fail(int code, const char *fmt, ...);
+int hrt_fail_hip(int hip_err, const char *what);
+#define HRT_HIP(call, what)                                   \
+    do {                                                      \
+        int e__ = (call);                                     \
+        if (e__ != 0) return hrt_fail_hip(e__, (what));       \
+    } while (0)
+
+double hrt_now_s(void);
+
+#endif

@@ -1,0 +1,467 @@
+/* problem.c -- host orchestration of the device-resident path (include/hrt_device.h).
+ *
+ * Host-side, once-per-call work of the reference that stays on the host:
+ *   precompute_materials  src/compute_paths.c:171-206   (17 x 12 floats, powf/sqrtf)
+ *   precompute_normals    src/compute_paths.c:208-224   (one cross/normalise per triangle)
+ *   Fibonacci launch set  src/compute_paths.c:443-451   (double libm; threads)
+ * plus what the reference has no need for: flattening the Scene into one 64-byte-per-
+ * triangle table in (mesh, face) order, the workspace layout, shard arithmetic, and the
+ * launch sequence of the HIP kernels (through the shim in ../hrt_kernels.hip).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "hrt_internal.h"
+
+/* ------------------------------------------------------------------ errors */
+
+static __thread char g_err[512];
+
+const char *hrt_last_error(void) { return g_err; }
+const char *hrt_version(void) { return "hermespy-rt_amd 0.1 (gfx950)"; }
+
+int hrt_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hrt_fail_hip(int hip_err, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hrt_hip_error_string(hip_err));
+    return HRT_E_HIP;
+}
+
+double hrt_now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------ problem */
+
+static uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+static inline Vec3 v_sub(Vec3 a, Vec3 b) { Vec3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+
+/* unit normal of (e1, e2): cross then divide by sqrtf of the squared length, in the operand
+ * order of inc/vec3.h:20-43 of the reference */
+static Vec3 unit_normal(Vec3 e1, Vec3 e2)
+{
+    Vec3 c = {e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x};
+    float len = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
+    Vec3 n = {c.x / len, c.y / len, c.z / len};
+    return n;
+}
+
+void hrt_problem_destroy(hrt_problem *p)
+{
+    if (!p) return;
+    if (p->d_blob) {
+        hrt_hip_set_device(p->device);
+        hrt_hip_free(p->d_blob);
+    }
+    free(p->h_tri); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
+    free(p);
+}
+
+int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                       const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t num_rx,
+                       size_t num_tx, int device, hrt_problem **out)
+{
+    if (!scene || !rx_pos || !tx_pos || !rx_vel || !tx_vel || !out)
+        return hrt_fail(HRT_E_INVALID, "hrt_problem_create: NULL argument");
+    if (num_rx == 0 || num_tx == 0 || num_rx > 65535 || num_tx > 65535)
+        return hrt_fail(HRT_E_INVALID, "hrt_problem_create: num_rx/num_tx must be in 1..65535");
+    if (!(f_ghz > 0.f)) return hrt_fail(HRT_E_INVALID, "carrier frequency must be > 0 GHz");
+    if (scene->num_meshes == 0) return hrt_fail(HRT_E_INVALID, "scene has no meshes");
+
+    uint64_t T = 0;
+    for (uint32_t i = 0; i < scene->num_meshes; ++i) {
+        const Mesh *m = &scene->meshes[i];
+        if (m->material_index >= HRT_NUM_MATERIALS)
+            return hrt_fail(HRT_E_INVALID, "mesh %u: material_index %u out of range (0..16)", i,
+                            m->material_index);
+        for (uint64_t k = 0; k < (uint64_t)m->num_triangles * 3; ++k)
+            if (m->is[k] >= m->num_vertices)
+                return hrt_fail(HRT_E_INVALID, "mesh %u: vertex index %u >= num_vertices %u", i,
+                                m->is[k], m->num_vertices);
+        T += m->num_triangles;
+    }
+    if (T > 0x7fffffffu) return hrt_fail(HRT_E_CAPACITY, "too many triangles");
+
+    hrt_problem *p = (hrt_problem *)calloc(1, sizeof *p);
+    if (!p) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    p->device = device;
+    p->num_tri = (uint32_t)T;
+    p->num_mesh = scene->num_meshes;
+    p->num_rx = (uint32_t)num_rx;
+    p->num_tx = (uint32_t)num_tx;
+    p->f_ghz = f_ghz;
+    /* src/compute_paths.c:483-488: f_hz = f_GHz * 1e9 (double product stored to float), then
+     * float arithmetic left to right */
+    float f_hz = (float)((double)f_ghz * 1e9);
+    p->fsl_mult = 4.f * HRT_PI_F * f_hz / HRT_C_F;
+    p->dop_mult = f_hz / HRT_C_F;
+
+    p->h_tri = (float *)calloc((size_t)(T ? T : 1) * HRT_TRI_FLOATS, sizeof(float));
+    p->h_mesh = (float *)calloc((size_t)p->num_mesh * HRT_MESH_FLOATS, sizeof(float));
+    p->h_mat = (float *)calloc(HRT_NUM_MATERIALS * HRT_MAT_FLOATS, sizeof(float));
+    p->h_tri_mesh = (uint32_t *)malloc((size_t)(T ? T : 1) * sizeof(uint32_t));
+    p->h_tri_face = (uint32_t *)malloc((size_t)(T ? T : 1) * sizeof(uint32_t));
+    if (!p->h_tri || !p->h_mesh || !p->h_mat || !p->h_tri_mesh || !p->h_tri_face) {
+        hrt_problem_destroy(p);
+        return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    }
+
+    /* flatten: one row per triangle, (mesh, face) order = the reference's loop order, which
+     * is what resolves equal-distance ties (src/compute_paths.c:253-275) */
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < scene->num_meshes; ++i) {
+        const Mesh *m = &scene->meshes[i];
+        for (uint32_t f = 0; f < m->num_triangles; ++f, ++j) {
+            Vec3 v1 = m->vs[m->is[3 * f]], v2 = m->vs[m->is[3 * f + 1]],
+                 v3 = m->vs[m->is[3 * f + 2]];
+            Vec3 e1 = v_sub(v2, v1), e2 = v_sub(v3, v1);
+            Vec3 n = unit_normal(e1, e2);
+            float *row = p->h_tri + (size_t)j * HRT_TRI_FLOATS;
+            row[0] = v1.x; row[1] = v1.y; row[2] = v1.z;
+            row[3] = e1.x; row[4] = e1.y; row[5] = e1.z;
+            row[6] = e2.x; row[7] = e2.y; row[8] = e2.z;
+            row[9] = n.x; row[10] = n.y; row[11] = n.z;
+            memcpy(&row[12], &i, 4);
+            p->h_tri_mesh[j] = i;
+            p->h_tri_face[j] = f;
+        }
+        float *mr = p->h_mesh + (size_t)i * HRT_MESH_FLOATS;
+        mr[0] = m->velocity.x; mr[1] = m->velocity.y; mr[2] = m->velocity.z;
+        memcpy(&mr[3], &m->material_index, 4);
+        /* eta only for materials the scene uses, like the reference */
+        hrt_eta *e = &p->eta[m->material_index];
+        hrt_material_eta(m->material_index, f_ghz, e);
+        float *mt = p->h_mat + (size_t)m->material_index * HRT_MAT_FLOATS;
+        memcpy(mt, e, 12 * sizeof(float));
+        mt[12] = hrt_materials[m->material_index].s;
+        mt[13] = (float)hrt_materials[m->material_index].s1_alpha;
+    }
+
+    /* one device blob: tri | mesh | mat | rx_pos | tx_pos | rx_vel | tx_vel (256-B aligned) */
+    uint64_t sz_tri = round_up((uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4, 256);
+    uint64_t sz_mesh = round_up((uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4, 256);
+    uint64_t sz_mat = round_up(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4, 256);
+    uint64_t sz_rx = round_up((uint64_t)num_rx * 12, 256), sz_tx = round_up((uint64_t)num_tx * 12, 256);
+    uint64_t total = sz_tri + sz_mesh + sz_mat + 2 * sz_rx + 2 * sz_tx;
+    int rc;
+    if ((rc = hrt_hip_set_device(device)) != 0) {
+        hrt_problem_destroy(p);
+        return hrt_fail_hip(rc, "hipSetDevice");
+    }
+    if ((rc = hrt_hip_malloc(&p->d_blob, total)) != 0) {
+        p->d_blob = NULL;
+        hrt_problem_destroy(p);
+        return hrt_fail_hip(rc, "hipMalloc(problem)");
+    }
+    uint8_t *b = (uint8_t *)p->d_blob;
+    p->d_tri = (const float *)b; b += sz_tri;
+    p->d_mesh = (const float *)b; b += sz_mesh;
+    p->d_mat = (const float *)b; b += sz_mat;
+    p->d_rx_pos = (const float *)b; b += sz_rx;
+    p->d_tx_pos = (const float *)b; b += sz_tx;
+    p->d_rx_vel = (const float *)b; b += sz_rx;
+    p->d_tx_vel = (const float *)b;
+    if ((rc = hrt_hip_h2d((void *)p->d_tri, p->h_tri, (uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4)) ||
+        (rc = hrt_hip_h2d((void *)p->d_mesh, p->h_mesh, (uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4)) ||
+        (rc = hrt_hip_h2d((void *)p->d_mat, p->h_mat, HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4)) ||
+        (rc = hrt_hip_h2d((void *)p->d_rx_pos, rx_pos, (uint64_t)num_rx * 12)) ||
+        (rc = hrt_hip_h2d((void *)p->d_tx_pos, tx_pos, (uint64_t)num_tx * 12)) ||
+        (rc = hrt_hip_h2d((void *)p->d_rx_vel, rx_vel, (uint64_t)num_rx * 12)) ||
+        (rc = hrt_hip_h2d((void *)p->d_tx_vel, tx_vel, (uint64_t)num_tx * 12))) {
+        hrt_problem_destroy(p);
+        return hrt_fail_hip(rc, "hipMemcpy(problem)");
+    }
+    *out = p;
+    return HRT_OK;
+}
+
+uint32_t hrt_problem_num_triangles(const hrt_problem *p) { return p->num_tri; }
+uint32_t hrt_problem_num_rx(const hrt_problem *p) { return p->num_rx; }
+uint32_t hrt_problem_num_tx(const hrt_problem *p) { return p->num_tx; }
+int hrt_problem_device(const hrt_problem *p) { return p->device; }
+
+int hrt_problem_eta_table(const hrt_problem *p, float *out)
+{
+    memcpy(out, p->eta, sizeof p->eta);
+    return HRT_OK;
+}
+
+int hrt_problem_normals(const hrt_problem *p, float *out)
+{
+    for (uint32_t j = 0; j < p->num_tri; ++j)
+        memcpy(out + 3 * (size_t)j, p->h_tri + (size_t)j * HRT_TRI_FLOATS + 9, 12);
+    return HRT_OK;
+}
+
+int hrt_problem_tri_ids(const hrt_problem *p, uint32_t *mesh_out, uint32_t *face_out)
+{
+    memcpy(mesh_out, p->h_tri_mesh, (size_t)p->num_tri * 4);
+    memcpy(face_out, p->h_tri_face, (size_t)p->num_tri * 4);
+    return HRT_OK;
+}
+
+/* ------------------------------------------------------------------ shards */
+
+static uint32_t shard_chunk(const hrt_shard *s) { return s->chunk ? s->chunk : 4096u; }
+
+static int shard_check(const hrt_shard *s)
+{
+    if (!s || s->count == 0 || s->rank >= s->count || s->num_paths == 0)
+        return hrt_fail(HRT_E_INVALID, "bad shard (rank %u of %u, %llu paths)", s ? s->rank : 0,
+                        s ? s->count : 0, s ? (unsigned long long)s->num_paths : 0ull);
+    if (shard_chunk(s) % 64u)
+        return hrt_fail(HRT_E_INVALID, "shard chunk %u is not a multiple of 64", shard_chunk(s));
+    if (s->num_bounces == 0 || s->num_bounces > 32)
+        return hrt_fail(HRT_E_INVALID, "num_bounces must be in 1..32");
+    return HRT_OK;
+}
+
+uint64_t hrt_shard_num_local(const hrt_shard *s)
+{
+    if (!s || s->count == 0 || s->rank >= s->count) return 0;
+    const uint64_t ch = shard_chunk(s), N = s->num_paths;
+    const uint64_t n_chunks = (N + ch - 1) / ch, rem = N % ch;
+    if (n_chunks <= s->rank) return 0;
+    const uint64_t mine = (n_chunks - s->rank + s->count - 1) / s->count;
+    uint64_t n = mine * ch;
+    const int owns_last = ((n_chunks - 1) % s->count) == s->rank;
+    if (owns_last && rem) n -= ch - rem;
+    return n;
+}
+
+uint64_t hrt_shard_global_path(const hrt_shard *s, uint64_t i)
+{
+    const uint64_t ch = shard_chunk(s);
+    return ((i / ch) * s->count + s->rank) * ch + i % ch;
+}
+
+/* ------------------------------------------------------------------ launch directions */
+
+typedef struct {
+    const hrt_shard *s;
+    float *out;
+    uint64_t i0, i1;
+} dirs_job;
+
+/* src/compute_paths.c:444-451.  k, phi, theta are FLOAT; acos/cos/sin are the DOUBLE libm
+ * functions applied to them; the products are rounded to float on store. */
+static void *dirs_worker(void *arg)
+{
+    dirs_job *jb = (dirs_job *)arg;
+    const float n_f = (float)jb->s->num_paths;   /* size_t -> float in "2.f * k / num_paths" */
+    const float golden = HRT_PI_F * (1.f + sqrtf(5.f));
+    for (uint64_t i = jb->i0; i < jb->i1; ++i) {
+        const uint64_t p = hrt_shard_global_path(jb->s, i);
+        const float k = (float)p + .5f;
+        const float phi = (float)acos((double)(1.f - 2.f * k / n_f));
+        const float theta = golden * k;
+        const double sp = sin((double)phi);
+        jb->out[3 * i] = (float)(cos((double)theta) * sp);
+        jb->out[3 * i + 1] = (float)(sin((double)theta) * sp);
+        jb->out[3 * i + 2] = (float)cos((double)phi);
+    }
+    return NULL;
+}
+
+int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads)
+{
+    if (!s || !out || s->count == 0 || s->rank >= s->count || s->num_paths == 0)
+        return hrt_fail(HRT_E_INVALID, "hrt_launch_dirs_host: bad shard");
+    const uint64_t n = hrt_shard_num_local(s);
+    if (num_threads <= 0) {
+        long c = sysconf(_SC_NPROCESSORS_ONLN);
+        num_threads = c > 0 ? (int)c : 1;
+    }
+    if (num_threads > 64) num_threads = 64;
+    if ((uint64_t)num_threads > n / 4096 + 1) num_threads = (int)(n / 4096 + 1);
+    pthread_t th[64];
+    dirs_job jb[64];
+    int started = 0;
+    for (int t = 0; t < num_threads; ++t) {
+        jb[t].s = s;
+        jb[t].out = out;
+        jb[t].i0 = n * (uint64_t)t / (uint64_t)num_threads;
+        jb[t].i1 = n * (uint64_t)(t + 1) / (uint64_t)num_threads;
+        if (t + 1 == num_threads || pthread_create(&th[t], NULL, dirs_worker, &jb[t]) != 0) {
+            /* last slice (or a thread that would not start): run here, to the end */
+            jb[t].i1 = n;
+            dirs_worker(&jb[t]);
+            break;
+        }
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    return HRT_OK;
+}
+
+/* ------------------------------------------------------------------ layout + trace */
+
+int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
+{
+    if (!p || !L) return hrt_fail(HRT_E_INVALID, "hrt_layout_query: NULL argument");
+    int rc = shard_check(s);
+    if (rc) return rc;
+    const uint64_t n0 = (uint64_t)p->num_tx * hrt_shard_num_local(s);
+    if (n0 == 0) return hrt_fail(HRT_E_INVALID, "shard %u of %u is empty", s->rank, s->count);
+    if (n0 >= 0xffffff00ull)
+        return hrt_fail(HRT_E_CAPACITY, "num_tx * local rays = %llu does not fit 32-bit ray ids",
+                        (unsigned long long)n0);
+    const uint64_t nb = s->num_bounces, cap = round_up(n0, HRT_BLOCK);
+    memset(L, 0, sizeof *L);
+    L->cap = cap;
+    uint64_t off = 0;
+    L->off_counts = off; off += round_up((nb + 2) * 4, 256);
+    L->off_los = off;    off += round_up((uint64_t)p->num_rx * p->num_tx * HRT_LOS_FLOATS * 4, 256);
+    L->off_hits = off;   L->hit_block_bytes = (uint64_t)HRT_HIT_FIELDS * cap * 4; off += nb * L->hit_block_bytes;
+    L->off_recs = off;   L->rec_block_bytes = (uint64_t)p->num_rx * HRT_REC_FIELDS * cap * 4; off += nb * L->rec_block_bytes;
+    L->off_masks = off;  off += nb * p->num_rx * (cap / 64) * 8;
+    L->total_bytes = off;
+    return HRT_OK;
+}
+
+int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs, void *d_ws,
+              uint64_t ws_bytes, void *stream, hrt_kernel_times *times)
+{
+    if (!p || !d_dirs || !d_ws) return hrt_fail(HRT_E_INVALID, "hrt_trace: NULL argument");
+    hrt_layout L;
+    int rc = hrt_layout_query(p, s, &L);
+    if (rc) return rc;
+    if (ws_bytes < L.total_bytes)
+        return hrt_fail(HRT_E_INVALID, "workspace too small: %llu < %llu bytes",
+                        (unsigned long long)ws_bytes, (unsigned long long)L.total_bytes);
+    if (((uintptr_t)d_ws & 255u) || ((uintptr_t)d_dirs & 3u))
+        return hrt_fail(HRT_E_INVALID, "workspace must be 256-byte aligned");
+
+    hrt_kparams K;
+    memset(&K, 0, sizeof K);
+    K.tri = p->d_tri; K.mesh = p->d_mesh; K.mat = p->d_mat;
+    K.num_tri = p->num_tri; K.num_mesh = p->num_mesh;
+    K.rx_pos = p->d_rx_pos; K.tx_pos = p->d_tx_pos; K.rx_vel = p->d_rx_vel; K.tx_vel = p->d_tx_vel;
+    K.num_rx = p->num_rx; K.num_tx = p->num_tx;
+    K.fsl_mult = p->fsl_mult; K.dop_mult = p->dop_mult;
+    K.dirs = d_dirs;
+    K.num_local = (uint32_t)hrt_shard_num_local(s);
+    K.num_bounces = s->num_bounces;
+    K.n0 = p->num_tx * K.num_local;
+    K.ws = (uint8_t *)d_ws;
+    K.cap = L.cap;
+    K.off_counts = L.off_counts; K.off_los = L.off_los; K.off_hits = L.off_hits;
+    K.hit_block_bytes = L.hit_block_bytes; K.off_recs = L.off_recs;
+    K.rec_block_bytes = L.rec_block_bytes; K.off_masks = L.off_masks;
+
+    HRT_HIP(hrt_hip_set_device(p->device), "hipSetDevice");
+    const uint32_t nb = s->num_bounces;
+    void *ev[2 * 34 + 2] = {0};
+    const uint32_t n_ev = times ? 2 * (nb + 2) : 0;
+    for (uint32_t i = 0; i < n_ev; ++i) {
+        rc = hrt_hip_event_create(&ev[i]);
+        if (rc) {
+            for (uint32_t k = 0; k < i; ++k) hrt_hip_event_destroy(ev[k]);
+            return hrt_fail_hip(rc, "hipEventCreate");
+        }
+    }
+    int hip = 0;
+#define STEP(call) do { if (!hip) hip = (call); } while (0)
+    STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0, (nb + 2) * 4, stream));
+    if (times) STEP(hrt_hip_event_record(ev[0], stream));
+    STEP(hrt_hip_launch_los(&K, stream));
+    if (times) STEP(hrt_hip_event_record(ev[1], stream));
+    for (uint32_t b = 0; b <= nb; ++b) {
+        if (times) STEP(hrt_hip_event_record(ev[2 + 2 * b], stream));
+        STEP(hrt_hip_launch_bounce(&K, b, stream));
+        if (times) STEP(hrt_hip_event_record(ev[3 + 2 * b], stream));
+    }
+    if (times && !hip) {
+        STEP(hrt_hip_stream_sync(stream));
+        memset(times, 0, sizeof *times);
+        if (!hip) STEP(hrt_hip_event_elapsed_ms(ev[0], ev[1], &times->los_ms));
+        for (uint32_t b = 0; b <= nb && !hip; ++b)
+            STEP(hrt_hip_event_elapsed_ms(ev[2 + 2 * b], ev[3 + 2 * b], &times->bounce_ms[b]));
+        times->num_bounce_launches = nb + 1;
+    }
+#undef STEP
+    for (uint32_t i = 0; i < n_ev; ++i) hrt_hip_event_destroy(ev[i]);
+    if (hip) return hrt_fail_hip(hip, "hrt_trace");
+    return HRT_OK;
+}
+
+void hrt_work_from_counts(const hrt_problem *p, const hrt_shard *s, const uint32_t *counts,
+                          hrt_stats *st)
+{
+    memset(st, 0, sizeof *st);
+    const uint64_t nb = s->num_bounces, T = p->num_tri, nrx = p->num_rx;
+    st->live[0] = (uint64_t)p->num_tx * hrt_shard_num_local(s);
+    for (uint64_t b = 1; b <= nb && b < 34; ++b) st->live[b] = counts[b];
+    uint64_t tests = (uint64_t)p->num_rx * p->num_tx * T;
+    for (uint64_t b = 0; b < nb; ++b) {
+        tests += T * (st->live[b] + nrx * st->live[b + 1]);
+        st->records += nrx * st->live[b + 1];
+    }
+    st->tests = tests;
+    st->device = p->device;
+}
+
+/* ------------------------------------------------------------------ device helpers */
+
+int hrt_device_count(int *out)
+{
+    int n = 0;
+    int rc = hrt_hip_device_count(&n);
+    if (rc) { *out = 0; return hrt_fail_hip(rc, "hipGetDeviceCount"); }
+    *out = n;
+    return HRT_OK;
+}
+int hrt_device_malloc(int device, void **out, uint64_t bytes)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_malloc(out, bytes), "hipMalloc");
+    return HRT_OK;
+}
+int hrt_device_free(int device, void *ptr)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_free(ptr), "hipFree");
+    return HRT_OK;
+}
+int hrt_device_upload(int device, void *dst, const void *src, uint64_t bytes)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_h2d(dst, src, bytes), "hipMemcpy H2D");
+    return HRT_OK;
+}
+int hrt_device_download(int device, void *dst, const void *src, uint64_t bytes)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_d2h(dst, src, bytes), "hipMemcpy D2H");
+    return HRT_OK;
+}
+int hrt_device_sync(int device, void *stream)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_stream_sync(stream), "hipStreamSynchronize");
+    return HRT_OK;
+}
+int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_mem_info(free_bytes, total_bytes), "hipMemGetInfo");
+    return HRT_OK;
+}

@@ -1,0 +1,70 @@
+/* hrt_kparams.h -- internal contract between the host C code and the HIP shim.
+ * Plain C structs; passed to the kernels by value. */
+#ifndef HRT_KPARAMS_H
+#define HRT_KPARAMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRT_NO_HIT 0xFFFFFFFFu
+#define HRT_NUM_MATERIALS 17
+#define HRT_TRI_FLOATS 16  /* v1(3) e1(3) e2(3) n(3) mesh_id(u32) pad(3) */
+#define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */
+#define HRT_MESH_FLOATS 4  /* velocity(3), material_index(u32) */
+#define HRT_BLOCK 256
+#define HRT_MAX_GRID 2048
+/* triangle tables up to this many bytes are staged in LDS (160 KiB per CU on gfx950, minus
+ * the material/endpoint tables); larger scenes read the table through the scalar cache. */
+#define HRT_LDS_TRI_BYTES_MAX (144u * 1024u)
+
+typedef struct {
+    /* scene (device pointers) */
+    const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
+    const float *mesh;    /* [num_mesh][HRT_MESH_FLOATS] */
+    const float *mat;     /* [17][HRT_MAT_FLOATS] */
+    uint32_t num_tri, num_mesh;
+    /* endpoints (device pointers, [n][3]) */
+    const float *rx_pos, *tx_pos, *rx_vel, *tx_vel;
+    uint32_t num_rx, num_tx;
+    /* src/compute_paths.c:483-488 */
+    float fsl_mult;       /* 4 pi f / c */
+    float dop_mult;       /* f / c */
+    /* shard */
+    const float *dirs;    /* [num_local][3] */
+    uint32_t num_local;
+    uint32_t num_bounces;
+    uint32_t n0;          /* num_tx * num_local */
+    uint32_t pad0;
+    /* workspace (see include/hrt_device.h) */
+    uint8_t *ws;
+    uint64_t cap;
+    uint64_t off_counts, off_los, off_hits, hit_block_bytes, off_recs, rec_block_bytes,
+        off_masks;
+} hrt_kparams;
+
+/* ---- the shim (hrt_kernels.hip).  All return 0 or a positive hipError_t. ---- */
+int hrt_hip_device_count(int *n);
+int hrt_hip_set_device(int dev);
+int hrt_hip_malloc(void **p, uint64_t bytes);
+int hrt_hip_free(void *p);
+int hrt_hip_h2d(void *dst, const void *src, uint64_t bytes);
+int hrt_hip_d2h(void *dst, const void *src, uint64_t bytes);
+int hrt_hip_memset_async(void *dst, int value, uint64_t bytes, void *stream);
+int hrt_hip_stream_sync(void *stream);
+int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
+int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
+int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream);
+/* events: opaque handles */
+int hrt_hip_event_create(void **ev);
+int hrt_hip_event_destroy(void *ev);
+int hrt_hip_event_record(void *ev, void *stream);
+int hrt_hip_event_elapsed_ms(void *start, void *stop, float *ms);
+const char *hrt_hip_error_string(int err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,164 @@
+// hermespy_rt -- Python surface of the compute_paths hot path (pybind11).
+//
+// Same module name, function signature, keyword names and ChannelInfo attributes as the
+// reference's binding (compute_paths_pybind11.cpp:99-210), so `import hermespy_rt` /
+// `from .rt import compute_paths` users switch by putting this module on the path:
+//
+//   compute_paths(mesh_filepath, rx_positions, tx_positions, rx_velocities, tx_velocities,
+//                 carrier_frequency, num_rx, num_tx, num_paths, num_bounces)
+//       -> (los: ChannelInfo, scatter: ChannelInfo)
+//   ChannelInfo.num_paths                  int   (1 / num_bounces*num_paths)
+//   ChannelInfo.directions_rx/_tx          float32  (num_rx, num_tx, num_paths, 3)
+//   ChannelInfo.a_te / a_tm                complex64 (num_rx, num_tx, num_paths)
+//   ChannelInfo.tau / freq_shift           float32  (num_rx, num_tx, num_paths)
+// The scatter path axis is bounce*num_paths + path.
+//
+// Deliberate differences from the reference binding (its defects):
+//   * C linkage is declared on every platform (the reference only does under _WIN32 and
+//     fails to import on Linux);
+//   * slots the tracer does not write (dead rays, blocked records' directions, the scatter
+//     directions_tx) read 0 instead of uninitialised heap memory;
+//   * the RaysInfo buffers the reference allocates (too small, Q13) and then throws away are
+//     not produced at all;
+//   * an unreadable scene file raises ValueError instead of exit(8); tracer errors raise
+//     RuntimeError; the GIL is released while the GPU works.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hermespy_rt.h"
+
+namespace py = pybind11;
+
+namespace {
+
+using farr = py::array_t<float, py::array::c_style | py::array::forcecast>;
+
+struct ChannelInfoPy {
+    size_t num_paths = 0;
+    py::array_t<float> directions_rx, directions_tx;
+    py::array_t<std::complex<float>> a_te, a_tm;
+    py::array_t<float> tau, freq_shift;
+};
+
+const Vec3 *as_vec3(const farr &a, size_t n, const char *name)
+{
+    if ((size_t)a.size() != 3 * n)
+        throw std::invalid_argument(std::string(name) + ": expected " + std::to_string(n) +
+                                    " x 3 values");
+    return reinterpret_cast<const Vec3 *>(a.data());
+}
+
+template <typename T>
+py::array_t<T> zeros(std::vector<size_t> shape)
+{
+    py::array_t<T> a(shape);
+    std::memset(a.mutable_data(), 0, sizeof(T) * (size_t)a.size());
+    return a;
+}
+
+void check_scene_file(const std::string &path)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw py::value_error("cannot open scene file: " + path);
+    char magic[3] = {0, 0, 0};
+    const size_t got = std::fread(magic, 1, 3, f);
+    std::fclose(f);
+    if (got != 3 || std::memcmp(magic, "HRT", 3) != 0)
+        throw py::value_error("not an HRT scene file: " + path);
+}
+
+// one channel block: float32 outputs are written in place; the complex amplitudes go through
+// re/im planes because the C ABI wants them separate
+struct ChannelBuffers {
+    ChannelInfoPy out;
+    std::vector<float> te_re, te_im, tm_re, tm_im;
+    ChannelInfo c{};
+    ChannelBuffers(size_t nrx, size_t ntx, size_t n)
+        : te_re(nrx * ntx * n), te_im(nrx * ntx * n), tm_re(nrx * ntx * n), tm_im(nrx * ntx * n)
+    {
+        out.num_paths = n;
+        out.directions_rx = zeros<float>({nrx, ntx, n, 3});
+        out.directions_tx = zeros<float>({nrx, ntx, n, 3});
+        out.tau = zeros<float>({nrx, ntx, n});
+        out.freq_shift = zeros<float>({nrx, ntx, n});
+        c.num_rays = (uint32_t)n;
+        c.directions_rx = reinterpret_cast<Vec3 *>(out.directions_rx.mutable_data());
+        c.directions_tx = reinterpret_cast<Vec3 *>(out.directions_tx.mutable_data());
+        c.a_te_re = te_re.data(); c.a_te_im = te_im.data();
+        c.a_tm_re = tm_re.data(); c.a_tm_im = tm_im.data();
+        c.tau = out.tau.mutable_data();
+        c.freq_shift = out.freq_shift.mutable_data();
+    }
+    void finish(size_t nrx, size_t ntx, size_t n)
+    {
+        out.a_te = py::array_t<std::complex<float>>(std::vector<size_t>{nrx, ntx, n});
+        out.a_tm = py::array_t<std::complex<float>>(std::vector<size_t>{nrx, ntx, n});
+        auto *te = out.a_te.mutable_data();
+        auto *tm = out.a_tm.mutable_data();
+        for (size_t i = 0; i < nrx * ntx * n; ++i) {
+            te[i] = {te_re[i], te_im[i]};
+            tm[i] = {tm_re[i], tm_im[i]};
+        }
+        te_re = {}; te_im = {}; tm_re = {}; tm_im = {};
+    }
+};
+
+std::tuple<ChannelInfoPy, ChannelInfoPy> compute_paths_py(
+    const std::string &mesh_filepath, farr rx_positions, farr tx_positions, farr rx_velocities,
+    farr tx_velocities, float carrier_frequency, unsigned long num_rx, unsigned long num_tx,
+    unsigned long num_paths, unsigned long num_bounces)
+{
+    if (!num_rx || !num_tx || !num_paths || !num_bounces)
+        throw std::invalid_argument("num_rx, num_tx, num_paths, num_bounces must be > 0");
+    const Vec3 *rxp = as_vec3(rx_positions, num_rx, "rx_positions");
+    const Vec3 *txp = as_vec3(tx_positions, num_tx, "tx_positions");
+    const Vec3 *rxv = as_vec3(rx_velocities, num_rx, "rx_velocities");
+    const Vec3 *txv = as_vec3(tx_velocities, num_tx, "tx_velocities");
+    check_scene_file(mesh_filepath);
+
+    ChannelBuffers los(num_rx, num_tx, 1), scat(num_rx, num_tx, num_bounces * num_paths);
+    int rc;
+    std::string err;
+    {
+        py::gil_scoped_release nogil;
+        Scene scene = scene_load(mesh_filepath.c_str());
+        rc = hrt_compute_paths_ex(&scene, rxp, txp, rxv, txv, carrier_frequency, num_rx, num_tx,
+                                  num_paths, num_bounces, &los.c, nullptr, &scat.c, nullptr,
+                                  nullptr);
+        if (rc != HRT_OK) err = hrt_last_error();
+        free_scene(&scene);
+    }
+    if (rc != HRT_OK)
+        throw std::runtime_error("hermespy_rt.compute_paths failed (" + std::to_string(rc) +
+                                 "): " + err);
+    los.finish(num_rx, num_tx, 1);
+    scat.finish(num_rx, num_tx, num_bounces * num_paths);
+    return {std::move(los.out), std::move(scat.out)};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(hermespy_rt, m)
+{
+    m.doc() = "MI355X-native compute_paths (drop-in for the hermespy-rt binding)";
+    py::class_<ChannelInfoPy>(m, "ChannelInfo")
+        .def_readonly("num_paths", &ChannelInfoPy::num_paths)
+        .def_readonly("directions_rx", &ChannelInfoPy::directions_rx)
+        .def_readonly("directions_tx", &ChannelInfoPy::directions_tx)
+        .def_readonly("a_te", &ChannelInfoPy::a_te)
+        .def_readonly("a_tm", &ChannelInfoPy::a_tm)
+        .def_readonly("tau", &ChannelInfoPy::tau)
+        .def_readonly("freq_shift", &ChannelInfoPy::freq_shift);
+    m.def("compute_paths", &compute_paths_py, "Compute gains and delays",
+          py::arg("mesh_filepath"), py::arg("rx_positions"), py::arg("tx_positions"),
+          py::arg("rx_velocities"), py::arg("tx_velocities"), py::arg("carrier_frequency"),
+          py::arg("num_rx"), py::arg("num_tx"), py::arg("num_paths"), py::arg("num_bounces"));
+    m.def("version", []() { return std::string(hrt_version()); });
+}

@@ -1,0 +1,225 @@
+"""Device-resident tracer: the hot path on torch-owned HBM buffers and streams.
+
+torch is plumbing here (device memory, streams, torch.distributed); the work is done by
+hrt_trace() of libhermespy_rt_amd.so on the CURRENT torch stream, called through the C ABI
+with raw device pointers.
+
+    tr = Tracer(scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths, num_bounces,
+                rank=0, world=1)
+    tr.trace()                 # asynchronous on torch's current stream
+    counts = tr.counts()       # [nb+2] numpy (syncs)
+    hits = tr.hits(b)          # dict name -> torch view of the first H_b elements
+    recs = tr.records(b)       # dict name -> [nrx, H_b] torch views, + 'unblocked' bool
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from . import lib as _lib
+
+
+class Tracer:
+    def __init__(self, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
+                 num_bounces, rank=0, world=1, chunk=0, device=None, host_threads=0):
+        import torch  # torch first: its HIP runtime is the one the library binds to
+
+        if not torch.cuda.is_available():
+            raise _lib.HrtError("no HIP device visible to torch; hermespy-rt_amd has no CPU path")
+        self.torch = torch
+        self.L = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        rx_pos = np.ascontiguousarray(np.asarray(rx_pos, np.float32).reshape(-1, 3))
+        tx_pos = np.ascontiguousarray(np.asarray(tx_pos, np.float32).reshape(-1, 3))
+        self.nrx, self.ntx = rx_pos.shape[0], tx_pos.shape[0]
+        rx_vel = np.ascontiguousarray(np.asarray(rx_vel, np.float32).reshape(self.nrx, 3))
+        tx_vel = np.ascontiguousarray(np.asarray(tx_vel, np.float32).reshape(self.ntx, 3))
+        self.num_paths, self.nb = int(num_paths), int(num_bounces)
+        self.f_ghz = float(f_ghz)
+        V3 = C.POINTER(abi.Vec3)
+
+        scene = self.L.scene_load(str(scene_path).encode())
+        try:
+            h = C.c_void_p()
+            _lib.check(self.L.hrt_problem_create(
+                C.byref(scene), rx_pos.ctypes.data_as(V3), tx_pos.ctypes.data_as(V3),
+                rx_vel.ctypes.data_as(V3), tx_vel.ctypes.data_as(V3), C.c_float(self.f_ghz),
+                self.nrx, self.ntx, self.device.index, C.byref(h)), "hrt_problem_create")
+            self.problem = h
+        finally:
+            abi.free_scene(scene)
+        self.num_tri = int(self.L.hrt_problem_num_triangles(self.problem))
+
+        self.shard = _lib.Shard(self.num_paths, rank, world, chunk, self.nb)
+        self.num_local = int(self.L.hrt_shard_num_local(C.byref(self.shard)))
+        self.layout = _lib.Layout()
+        _lib.check(self.L.hrt_layout_query(self.problem, C.byref(self.shard), C.byref(self.layout)),
+                   "hrt_layout_query")
+        self.cap = int(self.layout.cap)
+
+        # launch directions of this shard: host libm (bit-identical to the reference), once
+        dirs = np.empty((self.num_local, 3), np.float32)
+        _lib.check(self.L.hrt_launch_dirs_host(
+            C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)), host_threads),
+            "hrt_launch_dirs_host")
+        self.dirs_host = dirs
+        with torch.cuda.device(self.device):
+            self.dirs = torch.from_numpy(dirs).to(self.device)
+            self.ws = torch.empty(int(self.layout.total_bytes), dtype=torch.uint8, device=self.device)
+        assert self.ws.data_ptr() % 256 == 0
+        self.last_times = None
+
+    def close(self):
+        if getattr(self, "problem", None):
+            self.L.hrt_problem_destroy(self.problem)
+            self.problem = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ run
+    def trace(self, timed=False):
+        """Enqueue the whole path on torch's current stream.  timed=True records HIP events
+        around every launch on that stream, waits, and returns (los_ms, [bounce_ms...])."""
+        torch = self.torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        times = _lib.KernelTimes() if timed else None
+        _lib.check(self.L.hrt_trace(
+            self.problem, C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()),
+            C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream),
+            C.byref(times) if timed else None), "hrt_trace")
+        if timed:
+            n = int(times.num_bounce_launches)
+            self.last_times = (float(times.los_ms), [float(times.bounce_ms[i]) for i in range(n)])
+            return self.last_times
+        return None
+
+    # ------------------------------------------------------------------ views
+    def _view(self, off, n, dtype):
+        t = self.ws[off:off + n * 4]
+        return t.view(dtype)
+
+    def counts(self):
+        torch = self.torch
+        c = self._view(int(self.layout.off_counts), self.nb + 2, torch.int32).cpu().numpy()
+        c = c.astype(np.int64) & 0xFFFFFFFF
+        c[0] = self.ntx * self.num_local
+        return c
+
+    def los(self):
+        t = self._view(int(self.layout.off_los), self.nrx * self.ntx * _lib.LOS_FLOATS,
+                       self.torch.float32)
+        return t.cpu().numpy().reshape(self.nrx, self.ntx, _lib.LOS_FLOATS)
+
+    # whole-block views (all `cap` elements), used by sharding.pack_export
+    def counts_tensor(self):
+        return self._view(int(self.layout.off_counts), self.nb + 2, self.torch.int32)
+
+    def hit_block(self, b):
+        base = int(self.layout.off_hits) + b * int(self.layout.hit_block_bytes)
+        nf = len(_lib.HIT_FIELDS)
+        return self._view(base, nf * self.cap, self.torch.int32).view(nf, self.cap)
+
+    def rec_block(self, b):
+        base = int(self.layout.off_recs) + b * int(self.layout.rec_block_bytes)
+        nf = len(_lib.REC_FIELDS)
+        return self._view(base, self.nrx * nf * self.cap, self.torch.int32).view(self.nrx, nf, self.cap)
+
+    def mask_block(self, b):
+        words = self.cap // 64
+        moff = int(self.layout.off_masks) + b * self.nrx * words * 8
+        return self.ws[moff:moff + self.nrx * words * 8].view(self.torch.int32).view(self.nrx, 2 * words)
+
+    def hits(self, b, n=None):
+        """Fields of hit block b (rays that hit at bounce b, state after the bounce)."""
+        torch = self.torch
+        if n is None:
+            n = int(self.counts()[b + 1])
+        base = int(self.layout.off_hits) + b * int(self.layout.hit_block_bytes)
+        out = {}
+        for f, name in enumerate(_lib.HIT_FIELDS):
+            dt = torch.int32 if name in ("ray", "tri") else torch.float32
+            out[name] = self._view(base + f * self.cap * 4, self.cap, dt)[:n]
+        return out
+
+    def records(self, b, n=None):
+        """Scatter records of bounce b: dict name -> [nrx, H_b]; 'unblocked' bool [nrx, H_b]."""
+        torch = self.torch
+        if n is None:
+            n = int(self.counts()[b + 1])
+        base = int(self.layout.off_recs) + b * int(self.layout.rec_block_bytes)
+        nf = len(_lib.REC_FIELDS)
+        blk = self._view(base, self.nrx * nf * self.cap, torch.float32).view(self.nrx, nf, self.cap)
+        out = {name: blk[:, f, :n] for f, name in enumerate(_lib.REC_FIELDS)}
+        words = self.cap // 64
+        moff = int(self.layout.off_masks) + b * self.nrx * words * 8
+        m = self.ws[moff:moff + self.nrx * words * 8].view(torch.int64).view(self.nrx, words)
+        nw = (n + 63) // 64
+        bits = (m[:, :nw, None] >> torch.arange(64, device=self.device)) & 1
+        out["unblocked"] = bits.reshape(self.nrx, nw * 64)[:, :n].bool()
+        return out
+
+    def global_path(self, local_ray):
+        """tx, global path index of local ray ids (numpy or torch int tensor)."""
+        ch = int(self.shard.chunk) or 4096
+        tx = local_ray // self.num_local
+        i = local_ray - tx * self.num_local
+        p = ((i // ch) * int(self.shard.count) + int(self.shard.rank)) * ch + i % ch
+        return tx, p
+
+    def work(self, counts=None):
+        """Algorithmic work of the last trace (hrt_stats fields as a dict)."""
+        if counts is None:
+            counts = self.counts()
+        c32 = np.ascontiguousarray(counts, dtype=np.uint32)
+        st = _lib.Stats()
+        self.L.hrt_work_from_counts(self.problem, C.byref(self.shard),
+                                    c32.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st))
+        return dict(live=[int(st.live[i]) for i in range(self.nb + 1)], records=int(st.records),
+                    tests=int(st.tests))
+
+    # ------------------------------------------------------------------ dense (host) view
+    def to_dense(self, sentinel_u32=abi.SENTINEL_U32):
+        """Assemble the reference's dense [rx][tx][b][p] scatter arrays on the host from the
+        compact device result (global path indices; rays of other shards keep the sentinel).
+        Slow, for checking only -- the C drop-in compute_paths() has its own dense writer."""
+        torch = self.torch
+        nrx, ntx, nb, npth = self.nrx, self.ntx, self.nb, self.num_paths
+        shp = (nrx, ntx, nb, npth)
+
+        def sent(shape):
+            return np.full(shape, sentinel_u32, np.uint32).view(np.float32)
+
+        out = {k: sent(shp) for k in ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau", "dfs")}
+        out["directions_rx"] = sent(shp + (3,))
+        hit_tri = np.full((nb, ntx, npth), 0xFFFFFFFF, np.uint32)
+        hit_theta = sent((nb, ntx, npth))
+        fs0 = sent((nb, ntx, npth))
+        state = sent((nb, ntx, npth, 11))
+        counts = self.counts()
+        for b in range(nb):
+            n = int(counts[b + 1])
+            if n == 0:
+                continue
+            h = {k: v.cpu().numpy() for k, v in self.hits(b, n).items()}
+            ray = h["ray"].astype(np.int64) & 0xFFFFFFFF
+            tx, p = self.global_path(ray)
+            hit_tri[b, tx, p] = h["tri"].view(np.uint32)
+            hit_theta[b, tx, p] = h["theta"]
+            fs0[b, tx, p] = h["fs0"]
+            for k, name in enumerate(("ox", "oy", "oz", "dx", "dy", "dz", "a_te_re", "a_te_im",
+                                      "a_tm_re", "a_tm_im", "tau")):
+                state[b, tx, p, k] = h[name]
+            r = {k: v.cpu().numpy() for k, v in self.records(b, n).items()}
+            for rx in range(nrx):
+                ub = r["unblocked"][rx]
+                for k in ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau"):
+                    out[k][rx, tx, b, p] = r[k][rx]
+                out["dfs"][rx, tx[ub], b, p[ub]] = r["dfs"][rx][ub]
+                for c, name in enumerate(("dirx", "diry", "dirz")):
+                    out["directions_rx"][rx, tx[ub], b, p[ub], c] = r[name][rx][ub]
+        out.update(hit_tri=hit_tri, hit_theta=hit_theta, fs0=fs0, state=state, counts=counts)
+        return out

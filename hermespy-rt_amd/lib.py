@@ -1,0 +1,127 @@
+"""Loader and ctypes bindings of libhermespy_rt_amd.so (include/hermespy_rt.h, hrt_device.h).
+
+There is no fallback: if the library has not been built (make -C hermespy-rt_amd, or
+__graft_entry__.build()) loading raises, and every compute entry point needs a HIP device.
+"""
+import ctypes as C
+import os
+
+from . import LIB_DIR, abi
+
+LIB_PATH = os.path.join(LIB_DIR, "libhermespy_rt_amd.so")
+
+#: every symbol include/hermespy_rt.h and include/hrt_device.h declare
+EXPORTED = (
+    "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_last_error",
+    "hrt_version", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
+    "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
+    "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
+    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_layout_query", "hrt_trace",
+    "hrt_work_from_counts", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
+    "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
+)
+
+HIT_FIELDS = ("ray", "tri", "theta", "fs0", "ox", "oy", "oz", "dx", "dy", "dz",
+              "a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau")
+REC_FIELDS = ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau", "dirx", "diry", "dirz", "dfs")
+LOS_FLOATS = 8
+
+
+class Shard(C.Structure):
+    _fields_ = [("num_paths", C.c_uint64), ("rank", C.c_uint32), ("count", C.c_uint32),
+                ("chunk", C.c_uint32), ("num_bounces", C.c_uint32)]
+
+
+class Layout(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "total_bytes", "cap", "off_counts", "off_los", "off_hits", "hit_block_bytes",
+        "off_recs", "rec_block_bytes", "off_masks")]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("los_ms", C.c_float), ("bounce_ms", C.c_float * 33),
+                ("num_bounce_launches", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("live", C.c_uint64 * 34), ("records", C.c_uint64),
+                ("records_unblocked", C.c_uint64), ("tests", C.c_uint64),
+                ("t_setup_s", C.c_double), ("t_launch_dirs_s", C.c_double),
+                ("t_device_s", C.c_double), ("t_readback_s", C.c_double),
+                ("t_total_s", C.c_double), ("device", C.c_int)]
+
+
+class HrtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the bound library.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own HIP runtime (same soname, libamdhip64.so.7).  Two runtimes in one
+    # process do not work (the second sees no device), so when torch is installed it is
+    # imported FIRST: the library's DT_NEEDED then binds to the runtime torch already loaded
+    # and both share streams and allocations.  C callers without torch get /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise HrtError("%s not found: build it first (make -C hermespy-rt_amd). There is no "
+                       "CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    abi.bind_reference_abi(L)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    V3 = C.POINTER(abi.Vec3)
+    f32p = C.POINTER(C.c_float)
+    L.hrt_last_error.restype = C.c_char_p
+    L.hrt_version.restype = C.c_char_p
+    L.hrt_compute_paths_ex.restype = C.c_int
+    L.hrt_compute_paths_ex.argtypes = [
+        C.POINTER(abi.Scene), V3, V3, V3, V3, C.c_float, C.c_size_t, C.c_size_t, C.c_size_t,
+        C.c_size_t, C.POINTER(abi.ChannelInfo), C.POINTER(abi.RaysInfo),
+        C.POINTER(abi.ChannelInfo), C.POINTER(abi.RaysInfo), C.POINTER(Stats)]
+    L.hrt_problem_create.restype = C.c_int
+    L.hrt_problem_create.argtypes = [C.POINTER(abi.Scene), V3, V3, V3, V3, C.c_float, C.c_size_t,
+                                     C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.hrt_problem_destroy.argtypes = [vp]
+    L.hrt_problem_destroy.restype = None
+    for n in ("hrt_problem_num_triangles", "hrt_problem_num_rx", "hrt_problem_num_tx"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = u32
+    L.hrt_problem_device.argtypes = [vp]
+    L.hrt_problem_device.restype = C.c_int
+    L.hrt_problem_eta_table.argtypes = [vp, f32p]
+    L.hrt_problem_normals.argtypes = [vp, f32p]
+    L.hrt_problem_tri_ids.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.hrt_shard_num_local.argtypes = [C.POINTER(Shard)]
+    L.hrt_shard_num_local.restype = u64
+    L.hrt_shard_global_path.argtypes = [C.POINTER(Shard), u64]
+    L.hrt_shard_global_path.restype = u64
+    L.hrt_launch_dirs_host.argtypes = [C.POINTER(Shard), f32p, C.c_int]
+    L.hrt_launch_dirs_host.restype = C.c_int
+    L.hrt_layout_query.argtypes = [vp, C.POINTER(Shard), C.POINTER(Layout)]
+    L.hrt_layout_query.restype = C.c_int
+    L.hrt_trace.argtypes = [vp, C.POINTER(Shard), vp, vp, u64, vp, C.POINTER(KernelTimes)]
+    L.hrt_trace.restype = C.c_int
+    L.hrt_work_from_counts.argtypes = [vp, C.POINTER(Shard), C.POINTER(u32), C.POINTER(Stats)]
+    L.hrt_work_from_counts.restype = None
+    L.hrt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.hrt_device_malloc.argtypes = [C.c_int, C.POINTER(vp), u64]
+    L.hrt_device_free.argtypes = [C.c_int, vp]
+    L.hrt_device_upload.argtypes = [C.c_int, vp, vp, u64]
+    L.hrt_device_download.argtypes = [C.c_int, vp, vp, u64]
+    L.hrt_device_sync.argtypes = [C.c_int, vp]
+    L.hrt_device_mem_info.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
+    _lib = L
+    return L
+
+
+def check(rc, what="hermespy-rt_amd"):
+    if rc != 0:
+        raise HrtError("%s failed (%d): %s" % (what, rc, load().hrt_last_error().decode()))

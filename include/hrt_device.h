@@ -1,0 +1,156 @@
+/* hrt_device.h -- device-resident form of the compute_paths hot path (C ABI).
+ *
+ * compute_paths() (hermespy_rt.h) takes and returns HOST arrays in the reference's dense
+ * layout.  The functions here are the same path with everything resident in HBM and the
+ * result in COMPACT form -- what a multi-GPU caller (one process per GPU, ray-sharded) and
+ * bench.py drive.  compute_paths() itself is built on them.
+ *
+ * The caller owns the big buffers (launch directions, workspace): they are plain device
+ * pointers, e.g. torch tensors' data_ptr(), and `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  No torch or HIP types appear in any signature.
+ *
+ * Reference lines each piece replaces (relative to the reference repository):
+ *   hrt_problem_create   src/compute_paths.c:437-438 (precompute_materials/_normals, :171-224)
+ *                        + the scene/endpoint arguments of compute_paths (:419-429)
+ *   hrt_launch_dirs_host src/compute_paths.c:443-451 (Fibonacci sphere, double libm)
+ *   hrt_trace            src/compute_paths.c:460-472 (state init), :515-577 (LoS),
+ *                        :591-729 (bounce loop: moeller_trumbore :237-287, refl_coefs
+ *                        :300-344, scat_coefs :359-415)
+ */
+#ifndef HRT_DEVICE_H
+#define HRT_DEVICE_H
+
+#include "hermespy_rt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Everything small and read-only, uploaded once: flattened triangle table (v1, e1, e2, unit
+ * normal, mesh id; (mesh, face) order), per-mesh material/velocity, the eta table for the
+ * carrier frequency, RX/TX positions and velocities. */
+typedef struct hrt_problem hrt_problem;
+
+int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                       const Vec3 *rx_vel, const Vec3 *tx_vel, float carrier_frequency_GHz,
+                       size_t num_rx, size_t num_tx, int device, hrt_problem **out);
+void hrt_problem_destroy(hrt_problem *p);
+uint32_t hrt_problem_num_triangles(const hrt_problem *p);
+uint32_t hrt_problem_num_rx(const hrt_problem *p);
+uint32_t hrt_problem_num_tx(const hrt_problem *p);
+int hrt_problem_device(const hrt_problem *p);
+
+/* Host copies of what was uploaded (for tests): eta table [17][12] in the reference's
+ * MaterialPrecomputed field order (src/compute_paths.c:125-132); normals [T][3]; for flat
+ * triangle j its (mesh, face) pair. */
+int hrt_problem_eta_table(const hrt_problem *p, float *out17x12);
+int hrt_problem_normals(const hrt_problem *p, float *outTx3);
+int hrt_problem_tri_ids(const hrt_problem *p, uint32_t *mesh_out, uint32_t *face_out);
+
+/* A shard of the launch set.  The N = num_paths launch directions of every TX are cut into
+ * granules of `chunk` consecutive path indices dealt round-robin to `count` shards, so every
+ * shard sees the whole sphere (a contiguous block would be a polar cap with a very different
+ * hit rate).  Local ray i of shard r is global path
+ *     p = ((i / chunk) * count + r) * chunk + i % chunk .
+ * count = 1 is the unsharded problem. */
+typedef struct {
+    uint64_t num_paths;    /* global N per TX (the N in k/N of the Fibonacci sphere) */
+    uint32_t rank, count;  /* shard r of G */
+    uint32_t chunk;        /* granule; multiple of 64; 0 = 4096 */
+    uint32_t num_bounces;
+} hrt_shard;
+
+uint64_t hrt_shard_num_local(const hrt_shard *s);
+uint64_t hrt_shard_global_path(const hrt_shard *s, uint64_t local_i);
+
+/* Launch directions of this shard's local rays, [num_local][3] floats, on the HOST with the
+ * host libm (bit-identical to the reference's by construction).  num_threads <= 0: all
+ * cores. */
+int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads);
+
+/* ---- workspace layout ----
+ * cap = num_tx * num_local rounded up to 256 entries.  Every array below holds `cap`
+ * elements of 4 bytes unless noted, so a field is a contiguous, coalesced run.
+ *
+ *   counts      u32[num_bounces + 2]   counts[b] (b >= 1) = rays that hit at bounce b-1
+ *                                      = live rays entering bounce b; counts[0] = ntx*nloc
+ *   los         num_rx*num_tx entries of HRT_LOS_FLOATS floats
+ *   hit block b (b = 0 .. num_bounces-1), fields HRT_HIT_*:
+ *       the rays that hit something at bounce b, in arbitrary (wave-granular) order, with
+ *       their state AFTER the bounce.  It is also the live list of bounce b+1.
+ *   rec block b: for rx in 0..num_rx-1, fields HRT_REC_*: the scatter record of
+ *       (hit i of block b, rx) at element i; plus one bit per (rx, i) "unblocked".
+ *       A blocked record has a_* = tau = 0 and its dir/dfs elements are not written.
+ */
+enum {
+    HRT_HIT_RAY = 0,   /* u32: tx * num_local + local_i */
+    HRT_HIT_TRI,       /* u32: flat triangle index of the hit */
+    HRT_HIT_THETA,     /* incidence angle */
+    HRT_HIT_FS0,       /* launch Doppler term dot(tx_vel, d_launch) * f/c */
+    HRT_HIT_OX, HRT_HIT_OY, HRT_HIT_OZ, HRT_HIT_DX, HRT_HIT_DY, HRT_HIT_DZ,
+    HRT_HIT_A_TE_RE, HRT_HIT_A_TE_IM, HRT_HIT_A_TM_RE, HRT_HIT_A_TM_IM,
+    HRT_HIT_TAU,
+    HRT_HIT_FIELDS
+};
+enum {
+    HRT_REC_A_TE_RE = 0, HRT_REC_A_TE_IM, HRT_REC_A_TM_RE, HRT_REC_A_TM_IM,
+    HRT_REC_TAU,
+    HRT_REC_DIRX, HRT_REC_DIRY, HRT_REC_DIRZ,   /* directions_rx */
+    HRT_REC_DFS,       /* dot(d_to_rx - d_reflected, mesh_velocity) * f/c; the record's
+                          freq_shift is FS0 - DFS */
+    HRT_REC_FIELDS
+};
+enum {
+    HRT_LOS_STATUS = 0,  /* as float bits of u32: 0 coincident, 1 blocked, 2 clear */
+    HRT_LOS_A, HRT_LOS_TAU, HRT_LOS_DIRX, HRT_LOS_DIRY, HRT_LOS_DIRZ, HRT_LOS_FS,
+    HRT_LOS_FLOATS = 8
+};
+
+typedef struct {
+    uint64_t total_bytes;
+    uint64_t cap;               /* elements per array */
+    uint64_t off_counts;
+    uint64_t off_los;
+    uint64_t off_hits;          /* field f of block b at off_hits + b*hit_block_bytes + f*cap*4 */
+    uint64_t hit_block_bytes;
+    uint64_t off_recs;          /* field f of (b, rx) at off_recs + b*rec_block_bytes
+                                                       + (rx*HRT_REC_FIELDS + f)*cap*4 */
+    uint64_t rec_block_bytes;
+    uint64_t off_masks;         /* u64 words of (b, rx) at off_masks + (b*num_rx + rx)*(cap/64)*8 */
+} hrt_layout;
+
+int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
+
+/* Per-launch device times of one hrt_trace call, filled only when requested. */
+typedef struct {
+    float los_ms;
+    float bounce_ms[33];        /* launch b of the bounce kernel, b = 0 .. num_bounces */
+    uint32_t num_bounce_launches;
+} hrt_kernel_times;
+
+/* Enqueue the whole path on `stream`: zero the counters, LoS kernel, then num_bounces + 1
+ * launches of the bounce kernel (launch b scatters the hits of bounce b-1 to every RX and
+ * traces bounce b).  Asynchronous unless `times` != NULL, in which case HIP events are
+ * recorded around every launch on `stream` and the call returns after the stream drained.
+ * d_dirs: device [num_local][3] floats (this shard's launch directions). */
+int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs, void *d_workspace,
+              uint64_t workspace_bytes, void *stream, hrt_kernel_times *times);
+
+/* Algorithmic work of a finished trace from its (host copy of) counts: see hrt_stats. */
+void hrt_work_from_counts(const hrt_problem *p, const hrt_shard *s, const uint32_t *counts,
+                          hrt_stats *out);
+
+/* ---- thin helpers over the HIP runtime for C callers without one ---- */
+int hrt_device_count(int *out);
+int hrt_device_malloc(int device, void **out, uint64_t bytes);
+int hrt_device_free(int device, void *ptr);
+int hrt_device_upload(int device, void *dst, const void *src, uint64_t bytes);
+int hrt_device_download(int device, void *dst, const void *src, uint64_t bytes);
+int hrt_device_sync(int device, void *stream);
+/* total/free HBM bytes */
+int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRT_DEVICE_H */

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # a -m gpu run on a box without a GPU must fail loudly, not skip: nothing to do here.
+    pass
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    """The product's C-ABI library (HIP path).  Built by __graft_entry__.build()."""
+    import hermespy_rt_amd.lib as L
+    return L.load()
+
+
+@pytest.fixture(scope="session")
+def ref_lib():
+    """The REAL reference, built in place by `make -C oracle ref` (absent -> skip)."""
+    import ctypes
+    from hermespy_rt_amd import abi
+    p = os.path.join(REPO, "oracle", "_ref", "libhrt_ref.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/libhrt_ref.so not built (needs /root/reference)")
+    return abi.bind_reference_abi(ctypes.CDLL(p))

@@ -1,0 +1,101 @@
+"""GPU parity of the device-resident API (hrt_trace on torch-owned buffers): compact hit
+blocks / record blocks against the oracle's per-(bounce, ray) extras, and ray sharding:
+the union of G shards equals the unsharded run bit for bit (rays are independent)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+from . import configs as K
+from .parity import AMP_RTOL_INTERIM as AMP_RTOL, amp_error, assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracer(c, **kw):
+    from hermespy_rt_amd.device import Tracer
+    return Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"],
+                  c["f_ghz"], c["num_paths"], c["num_bounces"], **kw)
+
+
+CASES = {
+    "C1": K.C1,
+    "C3_20k": K.small(K.C3, 20000),
+    "C4_2tx_9k": K.small(K.C4_DOPPLER, 9000),
+    "C5_8x8_4k": K.small(K.C5, 4096),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_compact_blocks_vs_oracle(name):
+    c = CASES[name]
+    tr = _tracer(c)
+    tr.trace()
+    d = tr.to_dense()
+    ref = oracle.compute_paths(*K.args(c))
+    ex = ref["extras"]
+    nb = c["num_bounces"]
+    # live counts per bounce and the algorithmic test count
+    assert list(d["counts"][:nb + 1]) == [int(x) for x in ex["live"]]
+    assert tr.work()["tests"] == ex["tests"]
+    # hit indices: bit-exact
+    assert np.array_equal(d["hit_tri"], ex["hit_tri"])
+    # incidence angle: double acos rounded to float on both sides
+    hit = ex["hit_tri"] != 0xFFFFFFFF
+    assert np.allclose(d["hit_theta"][hit], ex["hit_theta"][hit], rtol=0, atol=2.4e-7)
+    # launch directions are the host libm's on both sides
+    assert_bit_equal(tr.dirs_host, ex["launch_dirs"], "launch_dirs")
+    # records
+    from hermespy_rt_amd.abi import written
+    s = ref["scat"]
+    w = written(s["a_te_re"])
+    assert np.array_equal(written(d["a_te_re"]), w)
+    assert_bit_equal(d["tau"], s["tau"], "tau")
+    assert_bit_equal(d["directions_rx"], s["directions_rx"], "directions_rx")
+    for pol in ("te", "tm"):
+        e = amp_error(d["a_%s_re" % pol], d["a_%s_im" % pol], s["a_%s_re" % pol], s["a_%s_im" % pol], w)
+        assert e <= AMP_RTOL, (pol, e)
+    # post-bounce ray state of every hit == the reference's RaysInfo snapshot rows (ntx == 1)
+    if len(c["tx_pos"]) == 1:
+        npth = c["num_paths"]
+        for b in range(nb):
+            snap = ref["scat_rays"][(b + 1) * npth:(b + 2) * npth]
+            h = hit[b, 0]
+            assert_bit_equal(d["state"][b, 0][h][:, :6], snap[h], "rays after bounce %d" % b)
+    tr.close()
+
+
+@pytest.mark.parametrize("world,chunk", [(2, 0), (3, 64), (4, 256)])
+def test_shards_union_equals_unsharded(world, chunk):
+    c = K.small(K.C3, 10000)
+    full = _tracer(c)
+    full.trace()
+    dfull = full.to_dense()
+    merged = None
+    total = 0
+    for r in range(world):
+        tr = _tracer(c, rank=r, world=world, chunk=chunk)
+        total += tr.num_local
+        tr.trace()
+        d = tr.to_dense()
+        if merged is None:
+            merged = d
+        else:
+            for k, v in d.items():
+                if k == "counts":
+                    merged[k] = merged[k] + v
+                    continue
+                sent = v.view(np.uint32) == (0xFFFFFFFF if k == "hit_tri" else 0x7FC0DEAD)
+                mv = merged[k].view(np.uint32)
+                # shards are disjoint: nobody overwrites a slot someone else wrote
+                msent = mv == (0xFFFFFFFF if k == "hit_tri" else 0x7FC0DEAD)
+                assert not np.any(~sent & ~msent)
+                mv[~sent] = v.view(np.uint32)[~sent]
+        tr.close()
+    assert total == c["num_paths"]
+    for k in dfull:
+        if k == "counts":
+            assert list(merged[k][:5]) == list(dfull[k][:5])
+        else:
+            assert_bit_equal(merged[k], dfull[k], k)
+    full.close()
