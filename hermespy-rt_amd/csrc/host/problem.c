@@ -465,3 +465,22 @@ int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
     HRT_HIP(hrt_hip_mem_info(free_bytes, total_bytes), "hipMemGetInfo");
     return HRT_OK;
 }
+
+/* ------------------------------------------------------------------ self test */
+
+int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t n)
+{
+    if (!in || !out || fn < 0 || fn > 4) return hrt_fail(HRT_E_INVALID, "hrt_selftest_math: bad argument");
+    void *d_in = NULL, *d_out = NULL;
+    int rc = hrt_device_malloc(device, &d_in, n * 4);
+    if (rc) return rc;
+    if ((rc = hrt_device_malloc(device, &d_out, n * 4))) { hrt_device_free(device, d_in); return rc; }
+    if (!(rc = hrt_device_upload(device, d_in, in, n * 4))) {
+        int e = hrt_hip_selftest_math(fn, (const float *)d_in, (float *)d_out, n, NULL);
+        if (e) rc = hrt_fail_hip(e, "hrt_selftest_math");
+        else if (!(rc = hrt_device_sync(device, NULL))) rc = hrt_device_download(device, out, d_out, n * 4);
+    }
+    hrt_device_free(device, d_in);
+    hrt_device_free(device, d_out);
+    return rc;
+}

@@ -25,10 +25,12 @@
 //     same table with wave-uniform (scalar-cache) loads.
 //   * Geometry is IEEE-exact and contraction-free (built with -ffp-contract=off, correctly
 //     rounded division/sqrt, denormals on): hit decisions, hit indices, reflected rays and
-//     delays are BIT-IDENTICAL to the C reference.  Only the transcendental functions
-//     (sin/cos/exp/acos feeding the amplitudes) go through the device math library; they are
-//     evaluated in double and rounded once to float, which is within 1 ulp of glibc's float
-//     functions.
+//     delays are BIT-IDENTICAL to the C reference.  The float libm calls of the shading code
+//     (sinf/cosf/expf/acosf) are bit-exact restatements of glibc 2.35's (hrt_libm.h, pinned
+//     exhaustively against the host libm by oracle/libm_probe.c), so amplitudes are
+//     bit-identical too; the one double-precision call, acos for the incidence angle, uses the
+//     device library and is rounded to float (agrees with glibc except with probability
+//     ~2^-29 per evaluation).
 //   * No MFMA: this is branchy intersection, not a contraction.
 #include <hip/hip_runtime.h>
 
@@ -36,6 +38,7 @@
 #include <stdio.h>
 
 #include "hrt_kparams.h"
+#include "hrt_libm.h"
 
 #pragma clang fp contract(off)
 
@@ -111,10 +114,11 @@ __device__ __forceinline__ float incidence_angle(F3 n, F3 d)
     return th;
 }
 
-__device__ __forceinline__ float sin_f(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float cos_f(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float exp_f(float x) { return (float)exp((double)x); }
-__device__ __forceinline__ float acos_f(float x) { return (float)acos((double)x); }
+// float libm calls of the shading code: bit-exact restatements of the host libm (hrt_libm.h)
+__device__ __forceinline__ float sin_f(float x) { return hrt_sinf(x); }
+__device__ __forceinline__ float cos_f(float x) { return hrt_cosf(x); }
+__device__ __forceinline__ float exp_f(float x) { return hrt_expf(x); }
+__device__ __forceinline__ float acos_f(float x) { return hrt_acosf(x); }
 
 // src/compute_paths.c:152-164
 __device__ __forceinline__ void complex_div(float ar, float ai, float br, float bi, float &cr,
@@ -438,6 +442,28 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
     }
 }
 
+// evaluates one of the hrt_libm.h functions (or the incidence-angle acos) over an array: the
+// GPU side of tests/test_gpu_libm.py
+__global__ void hrt_selftest_math_kernel(int fn, const float *in, float *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float y;
+    switch (fn) {
+    case 0: y = hrt_sinf(x); break;
+    case 1: y = hrt_cosf(x); break;
+    case 2: y = hrt_expf(x); break;
+    case 3: y = hrt_acosf(x); break;
+    default: {   // src/compute_paths.c:281-283 with dot(n, d) = x
+        float th = (float)acos((double)x);
+        if (th > kPi * 0.5f) th = kPi - th;
+        y = th;
+    }
+    }
+    out[i] = y;
+}
+
 thread_local char g_err[256];
 
 }  // namespace
@@ -504,6 +530,14 @@ int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream)
         hipLaunchKernelGGL(hrt_bounce_kernel<false>, dim3((uint32_t)blocks), dim3(HRT_BLOCK),
                            small, (hipStream_t)stream, *P, bounce);
     }
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(hrt_selftest_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, fn, d_in, d_out, n);
     return (int)hipGetLastError();
 }
 

@@ -150,6 +150,12 @@ int hrt_device_sync(int device, void *stream);
 /* total/free HBM bytes */
 int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
+/* Device self test: evaluates on the GPU, over n host floats, one of the float libm
+ * restatements the shading code uses -- fn 0 sinf, 1 cosf, 2 expf, 3 acosf (csrc/hrt_libm.h)
+ * -- or, fn 4, the incidence angle of src/compute_paths.c:281-283 for dot(n, d) = in[i]
+ * ((float)acos((double)x) folded to [0, pi/2]).  Tests compare the result with the host libm. */
+int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

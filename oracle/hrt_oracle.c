@@ -369,7 +369,8 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
     for (size_t rx = 1; rx < nrx; ++rx)
         memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
 
-    uint64_t n_tests = 0;
+    /* algorithmic count: the LoS pass is priced at nrx*ntx*T */
+    uint64_t n_tests = (uint64_t)nrx * ntx * T;
 
     /* ---- LoS (:515-577) ---- */
     for (size_t off = 0; off < nrx * ntx; ++off) los->a_te_im[off] = los->a_tm_im[off] = 0.f;
@@ -391,7 +392,6 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
                 continue;
             }
             hit_t h = closest_hit(tris, T, o, d);
-            n_tests += T;
             if (h.tri != HRT_NO_HIT && h.t <= 1.f) {
                 los->a_te_re[off] = los->a_tm_re[off] = los->tau[off] = 0.f;
                 los_rays->rays_active[off / 8] &= (uint8_t)~bit;
@@ -549,4 +549,24 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
     free(tris); free(dirs); free(st); free(active); free(live); free(hits); free(dfs);
     free(unblocked); free(live_tx); free(live_cnt);
     return 0;
+}
+
+/* Host libm over an array, for tests/test_gpu_libm.py: fn 0 sinf, 1 cosf, 2 expf, 3 acosf,
+ * 4 the incidence angle (src/compute_paths.c:281-283) for dot = in[i]. */
+void hrt_oracle_libm(int fn, const float *in, float *out, size_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        float x = in[i], y;
+        switch (fn) {
+        case 0: y = sinf(x); break;
+        case 1: y = cosf(x); break;
+        case 2: y = expf(x); break;
+        case 3: y = acosf(x); break;
+        default:
+            y = (float)acos((double)x);
+            if ((double)y > (double)HRT_PI_F / 2.) y = HRT_PI_F - y;
+        }
+        out[i] = y;
+    }
 }

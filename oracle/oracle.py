@@ -66,6 +66,8 @@ def lib():
             C.POINTER(_Chan), C.POINTER(_Rays), C.POINTER(_Chan), C.POINTER(_Rays),
             C.POINTER(_Opts)]
         _lib.hrt_oracle_max_threads.restype = C.c_int
+        _lib.hrt_oracle_libm.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t]
+        _lib.hrt_oracle_libm.restype = None
     return _lib
 
 
@@ -204,3 +206,14 @@ def compute_paths(scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths, 
         ex["tri_face"] = flat["tri_face"]
         res["extras"] = ex
     return res
+
+
+LIBM_FN = dict(sinf=0, cosf=1, expf=2, acosf=3, incidence_angle=4)
+
+
+def host_libm(fn, x):
+    """Evaluate the HOST libm's float function (what the reference calls) over an array."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().hrt_oracle_libm(LIBM_FN[fn], _p(x), _p(out), x.size)
+    return out

@@ -10,8 +10,6 @@ real/imaginary parts alone can be arbitrarily close to zero.
 import numpy as np
 
 AMP_RTOL = 1e-5
-#: interim: see test output; tightened once the device libm restatement lands
-AMP_RTOL_INTERIM = 1e-4
 
 
 def bits(a):
@@ -57,7 +55,7 @@ def amp_error(re, im, re_ref, im_ref, sentinel_mask=None):
     return float(np.max(err[~zero] / mag[~zero])) if (~zero).any() else 0.0
 
 
-def compare_dense(got, ref, amp_rtol=AMP_RTOL_INTERIM, check_rays=True, exact_freq_shift=False):
+def compare_dense(got, ref, amp_rtol=AMP_RTOL, check_rays=True, exact_freq_shift=False):
     """got/ref: dicts as returned by abi.run_compute_paths / oracle.compute_paths."""
     from hermespy_rt_amd.abi import written
     stats = {}
@@ -76,6 +74,12 @@ def compare_dense(got, ref, amp_rtol=AMP_RTOL_INTERIM, check_rays=True, exact_fr
         for pol in ("te", "tm"):
             e = amp_error(g["a_%s_re" % pol], g["a_%s_im" % pol], r["a_%s_re" % pol], r["a_%s_im" % pol], w)
             stats["%s.a_%s" % (blk, pol)] = e
+            # with the bit-exact device libm, amplitudes are normally bit-identical as well
+            nbits = 0
+            for part in ("re", "im"):
+                x, y = bits(g["a_%s_%s" % (pol, part)]), bits(r["a_%s_%s" % (pol, part)])
+                nbits += int(((x != y) & ~(np.isnan(g["a_%s_%s" % (pol, part)]) & np.isnan(r["a_%s_%s" % (pol, part)]))).sum())
+            stats["%s.a_%s.not_bit_equal" % (blk, pol)] = nbits
             assert e <= amp_rtol, "%s.a_%s: relative error %.3g > %.1g" % (blk, pol, e, amp_rtol)
     if check_rays:
         for k in ("los_rays", "los_active", "scat_rays", "scat_active"):

@@ -7,7 +7,7 @@ import pytest
 from oracle import oracle
 
 from . import configs as K
-from .parity import AMP_RTOL_INTERIM as AMP_RTOL, amp_error, assert_bit_equal
+from .parity import AMP_RTOL, amp_error, assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 
