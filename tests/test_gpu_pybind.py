@@ -1,0 +1,68 @@
+"""The drop-in Python module `hermespy_rt` (pybind11): the reference's own smoke test
+(test/test.py: simple_reflector.hrt, 10 000 rays, 3 bounces; float64 inputs; shape asserts)
+plus values against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+from . import configs as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import hermespy_rt_amd
+    import torch  # noqa: F401  (HIP runtime first, see hermespy_rt_amd.lib)
+    sys.path.insert(0, hermespy_rt_amd.LIB_DIR)
+    import hermespy_rt
+    return hermespy_rt
+
+
+def test_reference_smoke_test_contract(rt):
+    c = K.TEST_PY
+    num_rx = num_tx = 1
+    num_paths, num_bounces = 10000, 3
+    los, scatter = rt.compute_paths(
+        c["scene_path"], np.array(c["rx_pos"], dtype=np.float64), np.array(c["tx_pos"], dtype=np.float64),
+        np.array(c["rx_vel"], dtype=np.float64), np.array(c["tx_vel"], dtype=np.float64),
+        3.0, num_rx, num_tx, num_paths, num_bounces)
+    # test/test.py:61-87
+    assert los.num_paths == 1
+    assert (num_rx, num_tx, 1, 3) == los.directions_rx.shape == los.directions_tx.shape
+    assert (num_rx, num_tx, 1) == los.a_te.shape == los.a_tm.shape == los.tau.shape == los.freq_shift.shape
+    assert scatter.num_paths == num_bounces * num_paths
+    assert (num_rx, num_tx, scatter.num_paths, 3) == scatter.directions_rx.shape == scatter.directions_tx.shape
+    assert (num_rx, num_tx, scatter.num_paths) == scatter.a_te.shape == scatter.a_tm.shape \
+        == scatter.tau.shape == scatter.freq_shift.shape
+    assert los.a_te.dtype == np.complex64 and scatter.tau.dtype == np.float32
+    # values printed by the reference for this input
+    assert np.float32(los.tau[0, 0, 0]) == np.float32(3.335598e-12) or abs(los.tau[0, 0, 0] - 3.335598e-12) < 1e-18
+    assert los.a_te[0, 0, 0] == 1 + 0j
+    # against the oracle: written slots carry the reference's values, the rest reads 0
+    ref = oracle.compute_paths(*K.args(c))
+    w = ref["scat"]["a_te_re"].view(np.uint32) != oracle.SENTINEL_U32
+    assert w.sum() == 3690                                   # hits 3690 of 10000, then 0
+    tau_ref = np.where(w, ref["scat"]["tau"], 0).reshape(1, 1, -1)
+    assert np.array_equal(scatter.tau.view(np.uint32), tau_ref.astype(np.float32).view(np.uint32))
+    a_ref = np.where(w, ref["scat"]["a_te_re"] + 1j * ref["scat"]["a_te_im"], 0).reshape(1, 1, -1)
+    assert np.allclose(scatter.a_te, a_ref, rtol=1e-5, atol=0)
+    assert not scatter.directions_tx.any()                   # never written (Q1) -> zeros here
+
+
+def test_keyword_names_and_errors(rt):
+    c = K.small(K.C1, 100)
+    kw = dict(mesh_filepath=c["scene_path"], rx_positions=np.array(c["rx_pos"], np.float32),
+              tx_positions=np.array(c["tx_pos"], np.float32), rx_velocities=np.zeros((1, 3), np.float32),
+              tx_velocities=np.zeros((1, 3), np.float32), carrier_frequency=3.0, num_rx=1, num_tx=1,
+              num_paths=100, num_bounces=1)
+    los, sc = rt.compute_paths(**kw)
+    assert sc.a_te.shape == (1, 1, 100)
+    with pytest.raises(ValueError):
+        rt.compute_paths(**dict(kw, mesh_filepath="/nonexistent.hrt"))
+    with pytest.raises(Exception):
+        rt.compute_paths(**dict(kw, num_paths=0))
