@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch hrt_selftest_math_kernel over 32M floats (known traffic: "
+                         "128 MiB read + 128 MiB written, 4 B/lane) to calibrate PMC byte counters")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +146,15 @@ def main():
         if gather is not None:
             gather.run()
         return t
+
+    if args.calibrate:
+        import ctypes
+        from hermespy_rt_amd import lib as _l
+        n = 32 << 20
+        x = np.linspace(0.0, 1.0, n, dtype=np.float32)
+        y = np.empty_like(x)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        _l.check(_l.load().hrt_selftest_math(local_rank, 1, x.ctypes.data_as(f32p), y.ctypes.data_as(f32p), n))
 
     for _ in range(args.warmup):
         step(False)
@@ -191,8 +203,18 @@ def main():
     B_local = algorithmic_bytes(w["live"], nrx, tr.num_local, unb_local, w["records"] - unb_local)
     ach = B_local / (kern_ms_step * 1e-3) / 1e9
     tests_local = w["tests"]
+    # HBM bytes per launch from PMC counters: collected by profiles/collect_pmc.sh (separate
+    # rocprofv3 passes) for exactly this workload at N = 1, committed in profiles/
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if world == 1 and args.workload in pj:
+            traffic = pj[args.workload]["hbm_bytes_per_launch_avg"]
+            traffic_src = pj[args.workload]["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = dict(bound="hbm", kernel="hrt_bounce_kernel", achieved=ach, peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=B_local / n_launch,
                     avg_launch_ms=kern_ms_step / n_launch, launches_per_step=n_launch,
                     per_launch_ms=[float(x) for x in bm.mean(axis=0)],

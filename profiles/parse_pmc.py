@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn the two PMC passes of profiles/collect_pmc.sh into profiles/<tag>_pmc_*.csv (trimmed
+to our kernels) and profiles/pmc_traffic.json (corrected HBM bytes per launch of the bounce
+kernel), which bench.py reports as roofline.traffic for the same workload."""
+import csv
+import glob
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+workload = sys.argv[2] if len(sys.argv) > 2 else "c3"
+TRUE_KIB = 131072.0   # bench.py --calibrate: 32 Mi floats read, 32 Mi floats written
+
+raw = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(REPO, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv"))[0]
+    rows = [r for r in csv.DictReader(open(f)) if "hrt_" in r["Kernel_Name"]]
+    keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+            "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(os.path.join(HERE, "%s_pmc_%s_%s.csv" % (tag, ctr.lower(), workload)), "w", newline="") as fo:
+        w = csv.DictWriter(fo, keep)
+        w.writeheader()
+        for r in rows:
+            w.writerow({k: r[k] for k in keep})
+    cal = [float(r["Counter_Value"]) for r in rows if "selftest" in r["Kernel_Name"]][0]
+    b = [float(r["Counter_Value"]) for r in rows if "bounce" in r["Kernel_Name"]]
+    n_launch = len([r for r in rows if "los" in r["Kernel_Name"]])
+    per_step = len(b) // n_launch
+    raw[ctr] = dict(corr=TRUE_KIB / cal, per_launch=[sum(b[i::per_step]) / n_launch for i in range(per_step)])
+
+fetch = [x * raw["FETCH_SIZE"]["corr"] * 1024 for x in raw["FETCH_SIZE"]["per_launch"]]
+write = [x * raw["WRITE_SIZE"]["corr"] * 1024 for x in raw["WRITE_SIZE"]["per_launch"]]
+path = os.path.join(HERE, "pmc_traffic.json")
+allj = json.load(open(path)) if os.path.exists(path) else {}
+allj[workload] = dict(
+    n_gpus=1, kernel="hrt_bounce_kernel", round=tag,
+    source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/%s_pmc_*_%s.csv); "
+           "KiB counters, calibrated on a known-traffic launch of the same access pattern: "
+           "FETCH_SIZE x%.3f (gfx950 half-count), WRITE_SIZE x%.3f" % (tag, workload, raw["FETCH_SIZE"]["corr"], raw["WRITE_SIZE"]["corr"]),
+    fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
+    hbm_bytes_per_step=sum(fetch) + sum(write), hbm_bytes_per_launch_avg=(sum(fetch) + sum(write)) / len(fetch))
+json.dump(allj, open(path, "w"), indent=1)
+print(json.dumps(allj[workload], indent=1))
