@@ -111,7 +111,31 @@ def main():
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch hrt_selftest_math_kernel over 32M floats (known traffic: "
                          "128 MiB read + 128 MiB written, 4 B/lane) to calibrate PMC byte counters")
+    ap.add_argument("--dropin", action="store_true",
+                    help="instead of the HBM-resident bench: time the host-array drop-in C ABI "
+                         "(hrt_compute_paths_ex: launch dirs on the host, H2D, trace, D2H, dense "
+                         "scatter) once and print its phase times (the PCIe-inclusive figure)")
     args = ap.parse_args()
+
+    if args.dropin:
+        import torch  # noqa: F401
+        from hermespy_rt_amd import abi, lib
+        from tests import configs as K
+        c = workloads()[args.workload]
+        st = lib.Stats()
+        t0 = time.time()
+        abi.run_compute_paths(lib.load(), *K.args(c), with_rays=False, stats=st)
+        wall = time.time() - t0
+        nb = c["num_bounces"]
+        paths = int(st.records) + len(c["rx_pos"]) * len(c["tx_pos"])
+        print(json.dumps(dict(
+            mode="dropin (host arrays in/out, PCIe inclusive)", workload=describe(c),
+            t_total_s=st.t_total_s, t_setup_s=st.t_setup_s, t_launch_dirs_host_s=st.t_launch_dirs_s,
+            t_device_incl_h2d_s=st.t_device_s, t_readback_and_dense_scatter_s=st.t_readback_s,
+            wall_incl_python_alloc_s=wall, paths_per_s=paths / st.t_total_s,
+            tests_per_s=int(st.tests) / st.t_total_s, live=[int(st.live[i]) for i in range(nb + 1)],
+            records=int(st.records), records_unblocked=int(st.records_unblocked))))
+        return
 
     import torch
     import torch.distributed as dist

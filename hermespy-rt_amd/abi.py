@@ -138,7 +138,7 @@ def scene_to_numpy(scene):
 
 
 def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
-                      num_bounces, zero_freq_shift=None, with_rays=True):
+                      num_bounces, zero_freq_shift=None, with_rays=True, stats=None):
     """Call `lib.compute_paths` the way the reference's own callers do
     (compute_paths_pybind11.cpp:99-186, test/test.c:10-75) and return every output as numpy.
 
@@ -190,10 +190,19 @@ def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nu
 
     scene = lib.scene_load(str(scene_path).encode())
     try:
-        lib.compute_paths(C.byref(scene), rxp_c, txp_c, rxv_c, txv_c, C.c_float(f_ghz),
-                          nrx, ntx, npth, nb,
-                          C.byref(los_c), C.byref(lr) if with_rays else C.byref(lr),
-                          C.byref(scat_c), C.byref(sr))
+        if stats is not None or not with_rays:
+            # product-only entry point: status code, optional RaysInfo, counters
+            rc = lib.hrt_compute_paths_ex(C.byref(scene), rxp_c, txp_c, rxv_c, txv_c,
+                                          C.c_float(f_ghz), nrx, ntx, npth, nb, C.byref(los_c),
+                                          C.byref(lr) if with_rays else None, C.byref(scat_c),
+                                          C.byref(sr) if with_rays else None,
+                                          C.byref(stats) if stats is not None else None)
+            if rc != 0:
+                raise RuntimeError("hrt_compute_paths_ex failed (%d): %s" % (rc, lib.hrt_last_error().decode()))
+        else:
+            lib.compute_paths(C.byref(scene), rxp_c, txp_c, rxv_c, txv_c, C.c_float(f_ghz),
+                              nrx, ntx, npth, nb, C.byref(los_c), C.byref(lr),
+                              C.byref(scat_c), C.byref(sr))
         normals = [m["ns"] for m in scene_to_numpy(scene)]
     finally:
         free_scene(scene)

@@ -36,6 +36,7 @@
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "hrt_kparams.h"
 #include "hrt_libm.h"
@@ -66,8 +67,11 @@ struct Hit { uint32_t tri; float t; };
 
 // Closest hit over the whole triangle table, lowest index wins ties (strict '<').
 // `tri` points at LDS (broadcast reads) or at global memory (wave-uniform loads).
+//
+// Variant 0 ("plain"): the reference's test sequence as written -- three IEEE divisions per
+// triangle that survives the early-outs, per-lane divergent early-outs.
 template <typename TriPtr>
-__device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
+__device__ __forceinline__ Hit closest_hit_plain(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
@@ -92,6 +96,94 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F
     return {who, best};
 }
 
+// Variant 1 ("staged"): the same decisions with the divisions moved behind division-free
+// CERTAIN-REJECT tests on the numerators, and every skip wave-uniform.
+//
+// With a = |det| and N' = N * sign(det) (sign-bit xor; IEEE division is sign-symmetric, so
+// fl(N/det) == fl(N'/a) bit for bit), each reference test "fl(N'/a) < c" is implied by
+// "N' < fl(k*a)" for a constant k a few 2^-20 beyond c: the product's rounding (2^-24
+// relative) cannot bridge the margin and fl() is monotone.  A triangle is dropped only when
+// one of these certain-reject conditions holds for EVERY lane of the wave (wave-uniform
+// branch: no divergence, and an instruction costs the same for 1 or 64 active lanes anyway);
+// whatever survives goes through the reference's exact sequence, so accepted hits, their
+// distances and the lowest-index tie-break are bit-identical to variant 0.  Rejections are
+// written in "reject if <condition>" form so NaNs (never rejected by the reference's
+// comparisons) are not rejected here either.  Derivations: DESIGN.md, "staged intersection".
+//   R1  u < -eps        <=  Nu' < -fl(k1*a)            k1 = eps*(1+2^-18)
+//   R2  u > 1+eps       <=  Nu' >  fl(k2*a)            k2 = 1+2^-20
+//   R3  v < -eps        <=  Nv' < -fl(k1*a)
+//   R4  u+v > 1+eps     <=  fl(Nu'+Nv') > fl(k3*a)     k3 = 1+2^-19   (given R1..R3 not certain)
+//   R5  dist <= eps     <=  Nt' <  fl(k5*a)            k5 = eps*(1-2^-18)  (all triangles BEHIND
+//                                                       the ray origin fall here)
+//   R6  dist >= best    <=  Nt' >  fl(fl(best*a)*k2)
+constexpr float kK1 = 1.1920928955078125e-07f * (1.f + 0x1p-18f);
+constexpr float kK2 = 1.f + 0x1p-20f;
+constexpr float kK3 = 1.f + 0x1p-19f;
+constexpr float kK5 = 1.1920928955078125e-07f * (1.f - 0x1p-18f);
+
+// true iff p holds in every ACTIVE lane: one v_cmp into an SGPR pair + scalar compare (hipcc's
+// __all() goes through a v_cndmask/v_cmp_ne pair)
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
+__device__ __forceinline__ float xor_sign(float x, uint32_t sign_bit)
+{
+    return __uint_as_float(__float_as_uint(x) ^ sign_bit);
+}
+
+template <typename TriPtr>
+__device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
+{
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT;
+    for (uint32_t j = 0; j < num_tri; ++j) {
+        const float4 q0 = tri[4 * j], q1 = tri[4 * j + 1], q2 = tri[4 * j + 2];
+        const F3 v1 = {q0.x, q0.y, q0.z};
+        const F3 e1 = {q0.w, q1.x, q1.y};
+        const F3 e2 = {q1.z, q1.w, q2.x};
+        const F3 pv = cross3(d, e2);
+        const float det = dot3(e1, pv);
+        const F3 s = sub3(o, v1);
+        const float nu = dot3(s, pv);
+        const float a = fabsf(det);
+        const uint32_t sg = __float_as_uint(det) & 0x80000000u;
+        const float nu_s = xor_sign(nu, sg);
+        const float k1a = kK1 * a, k2a = kK2 * a;
+        bool rej = (a < kEps) | (nu_s < -k1a) | (nu_s > k2a);
+        if (wave_all(rej)) continue;
+        const F3 q = cross3(s, e1);
+        const float nv = dot3(d, q);
+        const float nv_s = xor_sign(nv, sg);
+        rej |= (nv_s < -k1a) | ((nu_s + nv_s) > kK3 * a);
+        if (wave_all(rej)) continue;
+        const float nt = dot3(e2, q);
+        const float nt_s = xor_sign(nt, sg);
+        rej |= (nt_s < kK5 * a) | (nt_s > (best * a) * kK2);
+        if (wave_all(rej)) continue;
+        // the reference's exact sequence (src/compute_paths.c:263-275) for the survivors
+        const float u = nu / det;
+        const float v = nv / det;
+        const float w = u + v;
+        const float dist = nt / det;
+        const bool miss = (det > -kEps && det < kEps) | (u < -kEps) | (u > kOnePlusEps) |
+                          (v < -kEps) | (w > kOnePlusEps);
+        const bool take = !rej & !miss & (dist > kEps) & (dist < best);
+        best = take ? dist : best;
+        who = take ? j : who;
+    }
+    return {who, best};
+}
+
+#ifndef HRT_TRACE_VARIANT_DEFAULT
+#define HRT_TRACE_VARIANT_DEFAULT 1
+#endif
+
+template <int VARIANT, typename TriPtr>
+__device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
+{
+    if constexpr (VARIANT == 0) return closest_hit_plain(tri, num_tri, o, d);
+    else return closest_hit_staged(tri, num_tri, o, d);
+}
+
 template <typename TriPtr>
 __device__ __forceinline__ F3 tri_normal(TriPtr tri, uint32_t j)
 {
@@ -107,7 +199,7 @@ __device__ __forceinline__ uint32_t tri_mesh(TriPtr tri, uint32_t j)
 
 // acos in double of the float dot product, stored to float, folded to [0, pi/2] with the
 // float pi (src/compute_paths.c:281-283).
-__device__ __forceinline__ float incidence_angle(F3 n, F3 d)
+__device__ __noinline__ float incidence_angle(F3 n, F3 d)
 {
     float th = (float)acos((double)dot3(n, d));
     if (th > kPi * 0.5f) th = kPi - th;   // (double)th > (double)pi_f/2. is the same test
@@ -134,33 +226,31 @@ __device__ __forceinline__ void complex_div(float ar, float ai, float br, float 
 //   m1 = eta_im, eta_sqrt_im, eta_inv_im, eta_inv_sqrt_im
 //   m2 = eta_abs, eta_abs_pow2, eta_abs_inv_sqrt, r
 //   m3 = s, s1_alpha, -, -
-__device__ __forceinline__ void fresnel(const float4 *mat, uint32_t mi, float th, float R[4])
+// Shading is per hit, not per triangle test: it is kept OUT OF LINE so that its double-
+// precision polynomial constants and temporaries do not inflate the register allocation of
+// the intersection loops (174 -> ~80 VGPRs: 2 -> 5+ waves per SIMD).
+__device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th)
 {
-    const float4 m0 = mat[4 * mi], m1 = mat[4 * mi + 1], m2 = mat[4 * mi + 2];
     const float s1 = sin_f(th);
-    if (m2.z * s1 > 1.f - kEps) {
-        R[0] = R[2] = 1.f;
-        R[1] = R[3] = 0.f;
-        return;
-    }
+    if (m2.z * s1 > 1.f - kEps) return make_float4(1.f, 0.f, 1.f, 0.f);
     const float s2 = s1 * s1;
     const float c2r = sqrtf(1.f + m0.z / m2.y * s2);
     const float c2i = sqrtf(1.f - m1.z / m2.y * s2);
     const float pr = m0.y * c2r - m1.y * c2i;
     const float pi = m0.y * c2i + m1.y * c2r;
     const float c1 = cos_f(th);
-    complex_div(c1 - pr, -pi, c1 + pr, pi, R[0], R[1]);
+    float4 R;
+    complex_div(c1 - pr, -pi, c1 + pr, pi, R.x, R.y);
     const float qr = m0.y * c1;
     const float qi = m1.y * c1;
-    complex_div(qr - c2r, qi - c2i, qr + c2r, qi + c2i, R[2], R[3]);
-    R[0] *= m2.w; R[1] *= m2.w; R[2] *= m2.w; R[3] *= m2.w;
+    complex_div(qr - c2r, qi - c2i, qr + c2r, qi + c2i, R.z, R.w);
+    R.x *= m2.w; R.y *= m2.w; R.z *= m2.w; R.w *= m2.w;
+    return R;
 }
 
-__device__ __forceinline__ void scatter_pattern(const float4 *mat, uint32_t mi, float th_s,
-                                                float th_i, float S[4])
+// src/compute_paths.c:359-415; s = scattering coefficient, alpha = s1_alpha (small integer)
+__device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s, float th_i)
 {
-    const float4 m3 = mat[4 * mi + 3];
-    const float s = m3.x, alpha = m3.y;   // alpha: small integer held as float
     const float cs = cos_f(th_s), ci = cos_f(th_i), si = sin_f(th_i);
     const float dth = fabsf(th_s - th_i);
     const float f = s * exp_f(-alpha * dth);
@@ -175,8 +265,10 @@ __device__ __forceinline__ void scatter_pattern(const float4 *mat, uint32_t mi, 
     float tmi = tm * sp;
     const float nrm = sqrtf(te * te + tei * tei + tm * tm + tmi * tmi);
     if (nrm > 1e-6f) { te /= nrm; tei /= nrm; tm /= nrm; tmi /= nrm; }
-    S[0] = te; S[1] = tei; S[2] = tm; S[3] = tmi;
+    return make_float4(te, tei, tm, tmi);
 }
+
+__device__ __noinline__ float acos_f_ool(float x) { return hrt_acosf(x); }
 
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
 {
@@ -210,7 +302,7 @@ enum : uint32_t {
 enum : uint32_t { R_A0 = 0, R_A1, R_A2, R_A3, R_TAU, R_DX, R_DY, R_DZ, R_DFS };
 
 // LDS image: [num_tri*4 float4 (if staged)] [17*4 float4 materials] [num_rx float4 RX pos]
-template <bool TRI_IN_LDS>
+template <bool TRI_IN_LDS, int VARIANT>
 __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams P,
                                                                const uint32_t b)
 {
@@ -287,13 +379,15 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
         if (!first) {
             const uint32_t pb = b - 1;
             F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
-            uint32_t mat = 0;
+            float mat_s = 0.f, mat_alpha = 1.f;
             if (valid) {
-                n = tri_normal(g_tri, htri);
-                const uint32_t mesh = tri_mesh(g_tri, htri);
+                n = tri_normal(tri, htri);
+                const uint32_t mesh = tri_mesh(tri, htri);
                 const float4 mm = reinterpret_cast<const float4 *>(P.mesh)[mesh];
                 mvel = {mm.x, mm.y, mm.z};
-                mat = __float_as_uint(mm.w);
+                const float4 m3 = l_mat[4u * __float_as_uint(mm.w) + 3u];
+                mat_s = m3.x;
+                mat_alpha = m3.y;
             }
             for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
                 bool unblocked = false;
@@ -302,7 +396,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
                     F3 w = sub3({rp.x, rp.y, rp.z}, o);
                     const float d2rx = sqrtf(dot3(w, w));
                     w = {w.x / d2rx, w.y / d2rx, w.z / d2rx};
-                    const Hit sh = closest_hit(tri, T, o, w);
+                    const Hit sh = closest_hit<VARIANT>(tri, T, o, w);
                     if (sh.tri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, sh.tri), w);
                     if (sh.tri != HRT_NO_HIT && sh.t <= 1.f) {
                         rec_field(P, pb, rx, R_A0)[i] = 0.f;
@@ -312,13 +406,12 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
                         rec_field(P, pb, rx, R_TAU)[i] = 0.f;
                     } else {
                         unblocked = true;
-                        const float th_s = acos_f(dot3(w, n));
-                        float S[4];
-                        scatter_pattern(l_mat, mat, th_s, theta, S);
-                        float o0 = a0 * S[0] - a1 * S[1];
-                        float o1 = a0 * S[1] + a1 * S[0];
-                        float o2 = a2 * S[2] - a3 * S[3];
-                        float o3 = a2 * S[3] + a3 * S[2];
+                        const float th_s = acos_f_ool(dot3(w, n));
+                        const float4 S = scatter_pattern(mat_s, mat_alpha, th_s, theta);
+                        float o0 = a0 * S.x - a1 * S.y;
+                        float o1 = a0 * S.y + a1 * S.x;
+                        float o2 = a2 * S.z - a3 * S.w;
+                        float o3 = a2 * S.w + a3 * S.z;
                         float f2 = P.fsl_mult * d2rx;
                         f2 *= f2;
                         if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
@@ -344,7 +437,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             uint32_t ntri = 0;
             float nth = 0.f;
             if (valid) {
-                const Hit h = closest_hit(tri, T, o, d);
+                const Hit h = closest_hit<VARIANT>(tri, T, o, d);
                 if (h.tri != HRT_NO_HIT) {
                     hit = true;
                     ntri = h.tri;
@@ -353,15 +446,14 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
                     const uint32_t mesh = tri_mesh(tri, h.tri);
                     const uint32_t mat =
                         __float_as_uint(reinterpret_cast<const float4 *>(P.mesh)[mesh].w);
-                    float R[4];
-                    fresnel(l_mat, mat, nth, R);
+                    float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
                     float fsl = P.fsl_mult * h.t;
                     fsl *= fsl;
-                    if (fsl > 1.f) { R[0] /= fsl; R[1] /= fsl; R[2] /= fsl; R[3] /= fsl; }
-                    const float b0 = a0 * R[0] - a1 * R[1];
-                    const float b1 = a0 * R[1] + a1 * R[0];
-                    const float b2 = a2 * R[2] - a3 * R[3];
-                    const float b3 = a2 * R[3] + a3 * R[2];
+                    if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
+                    const float b0 = a0 * R.x - a1 * R.y;
+                    const float b1 = a0 * R.y + a1 * R.x;
+                    const float b2 = a2 * R.z - a3 * R.w;
+                    const float b3 = a2 * R.w + a3 * R.z;
                     a0 = b0; a1 = b1; a2 = b2; a3 = b3;
                     tau += h.t / kC;
                     o = add3(mul3(d, h.t), o);
@@ -421,7 +513,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
         } else {
             // per-lane triangle loop over the global table (different rays per lane, same
             // triangle index: still wave-uniform addresses)
-            const Hit h = closest_hit(tri, P.num_tri, o, d);
+            const Hit h = closest_hit<0>(tri, P.num_tri, o, d);
             if (h.tri != HRT_NO_HIT && h.t <= 1.f) {
                 status = 1u;   // blocked (:548-554)
             } else {
@@ -512,6 +604,12 @@ int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream)
     uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
     if (blocks > HRT_MAX_GRID) blocks = HRT_MAX_GRID;
     if (blocks == 0) blocks = 1;
+    // HRT_TRACE_VARIANT=0 selects the plain (reference-sequence) intersection loop: kept for
+    // A/B timing and as an in-library cross-check of the staged loop (tests run both)
+    static const int variant = []() {
+        const char *v = getenv("HRT_TRACE_VARIANT");
+        return (v && *v) ? atoi(v) : HRT_TRACE_VARIANT_DEFAULT;
+    }();
     const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
     const bool in_lds = tri_bytes <= HRT_LDS_TRI_BYTES_MAX;
     const size_t small = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) +
@@ -519,16 +617,26 @@ int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream)
     if (in_lds) {
         const size_t lds = (size_t)tri_bytes + small;
         if (lds > 64u * 1024u) {
-            const hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&hrt_bounce_kernel<true>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const void *fn = variant == 0
+                                 ? reinterpret_cast<const void *>(&hrt_bounce_kernel<true, 0>)
+                                 : reinterpret_cast<const void *>(&hrt_bounce_kernel<true, 1>);
+            const hipError_t e =
+                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(hrt_bounce_kernel<true>, dim3((uint32_t)blocks), dim3(HRT_BLOCK), lds,
-                           (hipStream_t)stream, *P, bounce);
+        if (variant == 0)
+            hipLaunchKernelGGL((hrt_bounce_kernel<true, 0>), dim3((uint32_t)blocks), dim3(HRT_BLOCK),
+                               lds, (hipStream_t)stream, *P, bounce);
+        else
+            hipLaunchKernelGGL((hrt_bounce_kernel<true, 1>), dim3((uint32_t)blocks), dim3(HRT_BLOCK),
+                               lds, (hipStream_t)stream, *P, bounce);
     } else {
-        hipLaunchKernelGGL(hrt_bounce_kernel<false>, dim3((uint32_t)blocks), dim3(HRT_BLOCK),
-                           small, (hipStream_t)stream, *P, bounce);
+        if (variant == 0)
+            hipLaunchKernelGGL((hrt_bounce_kernel<false, 0>), dim3((uint32_t)blocks),
+                               dim3(HRT_BLOCK), small, (hipStream_t)stream, *P, bounce);
+        else
+            hipLaunchKernelGGL((hrt_bounce_kernel<false, 1>), dim3((uint32_t)blocks),
+                               dim3(HRT_BLOCK), small, (hipStream_t)stream, *P, bounce);
     }
     return (int)hipGetLastError();
 }
