@@ -186,12 +186,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    bounce_ms, los_ms = [], []
+    bounce_ms, los_ms, compact_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lm, bm = step(True)   # HIP events around every launch, on the launch stream
         los_ms.append(lm)
         bounce_ms.append(bm)
+        compact_ms.append(sum(tr.last_compact_ms))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -243,7 +244,9 @@ def main():
                     avg_launch_ms=kern_ms_step / n_launch, launches_per_step=n_launch,
                     per_launch_ms=[float(x) for x in bm.mean(axis=0)],
                     kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
-                    note="VALU-bound brute-force intersection: see DESIGN.md (valu fraction)")
+                    compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
+                    trace_variant=os.environ.get("HRT_TRACE_VARIANT", "default(2: packet culling)"),
+                    note="VALU-bound intersection work, not HBM-bound: see DESIGN.md section 6")
 
     if rank == 0:
         out = dict(

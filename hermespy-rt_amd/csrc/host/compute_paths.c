@@ -39,7 +39,8 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
 }
 
 typedef struct {
-    void *d_dirs, *d_ws;
+    void *d_dirs, *d_ws, *d_order;
+    uint32_t *h_order;      /* coherent launch order of one batch */
     float *h_dirs;          /* launch directions of the whole sphere, [np][3] */
     uint32_t *h_counts;
     float *h_los;
@@ -56,6 +57,8 @@ typedef struct {
 static void work_free(work_t *w)
 {
     if (w->d_dirs) hrt_device_free(w->device, w->d_dirs);
+    if (w->d_order) hrt_device_free(w->device, w->d_order);
+    free(w->h_order);
     if (w->d_ws) hrt_device_free(w->device, w->d_ws);
     free(w->h_dirs); free(w->h_counts); free(w->h_los); free(w->ray); free(w->tri);
     for (int k = 0; k < 6; ++k) free(w->st[k]);
@@ -180,6 +183,9 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         const uint64_t cap = L.cap;
         if ((rc = hrt_device_malloc(w.device, &w.d_ws, L.total_bytes))) goto done;
         if ((rc = hrt_device_malloc(w.device, &w.d_dirs, n_loc_max * 12))) goto done;
+        if ((rc = hrt_device_malloc(w.device, &w.d_order, n_loc_max * 4))) goto done;
+        w.h_order = (uint32_t *)malloc(n_loc_max * 4);
+        if (!w.h_order) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
         w.h_counts = (uint32_t *)calloc(nb + 2, 4);
         w.h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
         w.ray = (uint32_t *)malloc(cap * 4);
@@ -209,8 +215,10 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             src = w.dirs_batch;
         }
         t0 = hrt_now_s();
+        if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
         if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;
-        if ((rc = hrt_trace(prob, &s, (const float *)w.d_dirs, w.d_ws, L.total_bytes, NULL, NULL))) goto done;
+        if ((rc = hrt_device_upload(w.device, w.d_order, w.h_order, n_loc * 4))) goto done;
+        if ((rc = hrt_trace(prob, &s, (const float *)w.d_dirs, (const uint32_t *)w.d_order, w.d_ws, L.total_bytes, NULL, NULL))) goto done;
         if ((rc = hrt_device_sync(w.device, NULL))) goto done;
         t_dev += hrt_now_s() - t0;
 

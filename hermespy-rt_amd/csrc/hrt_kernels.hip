@@ -173,15 +173,221 @@ __device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, uint32_t num_tri, 
     return {who, best};
 }
 
+// Variant 2 ("packet"): the wave is treated as a RAY PACKET.  Per trace, wave reductions give a
+// bounding ball of the 64 origins (centre oc, radius ro) and a bounding cone of the 64
+// directions (axis ax, half-angle alpha); then the lanes swap roles -- lane l tests TRIANGLE
+// 64k+l against the packet -- and a ballot yields the candidate triangles, which are walked in
+// ascending index order through the staged test above.  A triangle is culled only when the
+// reference's float test is PROVABLY rejecting for every ray of the packet.
+//
+// The proof works in numerator space, where the float error is an absolute bound with no
+// conditioning blow-up (u = 2^-24, eps = 2^-23; E_* bound |float numerator - exact numerator|
+// for any origin with |o - v1| <= S; derivation in DESIGN.md "packet culling"):
+//     E_d = 16 eps |e1||e2|        E_u = 16 eps S |e2|       E_v = 16 eps S |e1|
+//     E_t = 16 eps S |e1||e2|      (the worst-case analysis gives 10u, i.e. 3x below these)
+// With sigma = sign(det_f) and a_f = |det_f|, acceptance by the reference requires
+//     sigma*Nu >= -(2 eps (|N| + E_d) + E_u)                         (u >= -eps)
+//     sigma*Nv >= -(2 eps (|N| + E_d) + E_v)                         (v >= -eps)
+//     sigma*(Nu + Nv - det) <= 4 eps (|N| + E_d) + E_u + E_v + E_d   (u + v <= 1 + eps)
+//     sigma*Nt > -E_t                                                (dist > eps)
+// on the EXACT numerators Nu = d.(e2 x s), Nv = d.(s x e1), Nu+Nv-det = d.((e2-e1) x (s-e1)),
+// Nt = s.N, det = -d.N (s = o - v1, N = e1 x e2).  Each is a linear form d.G(o) with G affine
+// in o, so over the packet it is bounded by |G(oc)| * cos(angle(ax, G(oc)) -/+ alpha) plus
+// |edge| * ro.  sigma is the same for all rays iff the cone does not straddle the plane
+// (|N| (|ax.n| cos(alpha) - sin(alpha)) > 2 E_d); otherwise the triangle is kept.  Tolerances
+// are doubled and a 1e-4 relative slack covers |d| != 1 and the roundoff of this test itself.
+struct Packet {
+    F3 oc, ax;
+    float ro, cosa, sina;
+    bool usable;
+};
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// must be called by ALL lanes of the wave (valid = lane carries a real ray)
+__device__ __noinline__ Packet packet_bounds(F3 o, F3 d, bool valid)
+{
+    const float big = 3.0e38f;
+    Packet P;
+    const float lox = wave_min_f(valid ? o.x : big), hix = wave_max_f(valid ? o.x : -big);
+    const float loy = wave_min_f(valid ? o.y : big), hiy = wave_max_f(valid ? o.y : -big);
+    const float loz = wave_min_f(valid ? o.z : big), hiz = wave_max_f(valid ? o.z : -big);
+    P.oc = {0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz)};
+    const F3 ext = {hix - lox, hiy - loy, hiz - loz};
+    // half diagonal of the bounding box, rounded up
+    P.ro = 0.5f * sqrtf(dot3(ext, ext)) * 1.00001f + 1e-6f * (fabsf(P.oc.x) + fabsf(P.oc.y) + fabsf(P.oc.z));
+    const F3 sd = {wave_sum_f(valid ? d.x : 0.f), wave_sum_f(valid ? d.y : 0.f),
+                   wave_sum_f(valid ? d.z : 0.f)};
+    const float n2 = dot3(sd, sd);
+    const float inv = 1.f / sqrtf(fmaxf(n2, 1e-30f));
+    P.ax = {sd.x * inv, sd.y * inv, sd.z * inv};
+    float c = wave_min_f(valid ? dot3(d, P.ax) : 1.f);
+    c = c * (1.f - 1e-5f) - 1e-6f;   // |d| is 1 within ~1e-6: widen the cone instead
+    P.cosa = c;
+    P.sina = sqrtf(fmaxf(0.f, 1.f - c * c));
+    // wide packets (half-angle > ~60 deg) or degenerate axis: culling cannot pay
+    P.usable = (n2 > 1e-12f) && (c > 0.5f) && (lox <= hix);
+    return P;
+}
+
+// upper / lower bound of d.G over the cone (|d| = 1), G given with its norm
+__device__ __forceinline__ void cone_range(const Packet &P, F3 G, float &lo, float &hi)
+{
+    const float g = sqrtf(dot3(G, G));
+    const float c = (g > 0.f) ? dot3(P.ax, G) / g : 0.f;
+    const float s = sqrtf(fmaxf(0.f, 1.f - c * c));
+    hi = (c >= P.cosa) ? g : g * (c * P.cosa + s * P.sina);
+    lo = (c <= -P.cosa) ? -g : g * (c * P.cosa - s * P.sina);
+    const float slack = 1e-4f * g;
+    hi += slack;
+    lo -= slack;
+}
+
+// true iff triangle row (q0,q1,q2) with lengths L = (|e1|, |e2|, |e2-e1|, |N|) is provably
+// rejected by the reference's test for every ray of the packet
+__device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 q1, float4 q2,
+                                             float4 L)
+{
+    constexpr float kE = 16.f * kEps;
+    const F3 v1 = {q0.x, q0.y, q0.z};
+    const F3 e1 = {q0.w, q1.x, q1.y};
+    const F3 e2 = {q1.z, q1.w, q2.x};
+    const F3 nh = {q2.y, q2.z, q2.w};
+    const F3 sc = sub3(P.oc, v1);
+    const float S = sqrtf(dot3(sc, sc)) * 1.00001f + P.ro;
+    const float Ed = kE * L.x * L.y;
+    const float dn = dot3(P.ax, nh);
+    // all rays on one side of the plane's direction field, so sigma is constant
+    if (!(L.w * (fabsf(dn) * P.cosa - P.sina) > 3.f * Ed + 1e-30f)) return false;
+    const bool pos = dn < 0.f;   // sigma = sign(det) = sign(-d.N) = +1
+    const float Eu = kE * S * L.y, Ev = kE * S * L.x, Et = kE * S * L.x * L.y;
+    const float aN = L.w * 1.0001f + Ed;
+    const float tol_u = 2.f * (2.f * kEps * aN + Eu);
+    const float tol_v = 2.f * (2.f * kEps * aN + Ev);
+    const float tol_w = 2.f * (4.f * kEps * aN + Eu + Ev + Ed);
+    // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - ro, h + ro]
+    const float h = dot3(sc, nh);
+    const float snt_max = pos ? (h + P.ro) : -(h - P.ro);   // divided by |N|
+    bool cull = snt_max * L.w < -2.f * Et - 1e-4f * L.w * (fabsf(h) + P.ro);
+    const F3 Gu = cross3(e2, sc);
+    const F3 Gv = cross3(sc, e1);
+    const F3 Nn = cross3(e1, e2);
+    const F3 Gw = add3(add3(Gu, Gv), Nn);
+    float lo, hi;
+    cone_range(P, Gu, lo, hi);
+    cull |= ((pos ? hi : -lo) + L.y * P.ro * 1.0001f) < -tol_u;
+    cone_range(P, Gv, lo, hi);
+    cull |= ((pos ? hi : -lo) + L.x * P.ro * 1.0001f) < -tol_v;
+    cone_range(P, Gw, lo, hi);
+    cull |= ((pos ? lo : -hi) - L.z * P.ro * 1.0001f) > tol_w;
+    return cull;
+}
+
+// one staged test of triangle j for every lane; `rej0` lanes do not participate
+#define HRT_STAGED_BODY(J)                                                                      \
+    {                                                                                           \
+        const float4 q0 = tri[4 * (J)], q1 = tri[4 * (J) + 1], q2 = tri[4 * (J) + 2];           \
+        const F3 v1 = {q0.x, q0.y, q0.z};                                                       \
+        const F3 e1 = {q0.w, q1.x, q1.y};                                                       \
+        const F3 e2 = {q1.z, q1.w, q2.x};                                                       \
+        const F3 pv = cross3(d, e2);                                                            \
+        const float det = dot3(e1, pv);                                                         \
+        const F3 s = sub3(o, v1);                                                               \
+        const float nu = dot3(s, pv);                                                           \
+        const float a = fabsf(det);                                                             \
+        const uint32_t sg = __float_as_uint(det) & 0x80000000u;                                 \
+        const float nu_s = xor_sign(nu, sg);                                                    \
+        const float k1a = kK1 * a, k2a = kK2 * a;                                               \
+        bool rej = !valid | (a < kEps) | (nu_s < -k1a) | (nu_s > k2a);                          \
+        if (!wave_all(rej)) {                                                                   \
+            const F3 q = cross3(s, e1);                                                         \
+            const float nv = dot3(d, q);                                                        \
+            const float nv_s = xor_sign(nv, sg);                                                \
+            rej |= (nv_s < -k1a) | ((nu_s + nv_s) > kK3 * a);                                   \
+            if (!wave_all(rej)) {                                                               \
+                const float nt = dot3(e2, q);                                                   \
+                const float nt_s = xor_sign(nt, sg);                                            \
+                rej |= (nt_s < kK5 * a) | (nt_s > (best * a) * kK2);                            \
+                if (!wave_all(rej)) {                                                           \
+                    const float u = nu / det;                                                   \
+                    const float v = nv / det;                                                   \
+                    const float w = u + v;                                                      \
+                    const float dist = nt / det;                                                \
+                    const bool miss = (det > -kEps && det < kEps) | (u < -kEps) |               \
+                                      (u > kOnePlusEps) | (v < -kEps) | (w > kOnePlusEps);      \
+                    const bool take = !rej & !miss & (dist > kEps) & (dist < best);             \
+                    best = take ? dist : best;                                                  \
+                    who = take ? (J) : who;                                                     \
+                }                                                                               \
+            }                                                                                   \
+        }                                                                                       \
+    }
+
+// ALL lanes of the wave must call this (uniform control flow); invalid lanes carry dummies.
+template <typename TriPtr>
+__device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, TriPtr cull, uint32_t num_tri,
+                                                  F3 o, F3 d, bool valid, uint32_t lane)
+{
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT;
+    const Packet P = packet_bounds(o, d, valid);
+    if (!P.usable) {
+        for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
+        return {who, best};
+    }
+    for (uint32_t base = 0; base < num_tri; base += 64u) {
+        const uint32_t jl = base + lane;
+        bool cand = false;
+        if (jl < num_tri)
+            cand = !packet_culls(P, tri[4 * jl], tri[4 * jl + 1], tri[4 * jl + 2], cull[jl]);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        while (m) {   // ascending triangle index: the reference's tie-break order
+            const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            HRT_STAGED_BODY(j)
+        }
+    }
+    return {who, best};
+}
+
 #ifndef HRT_TRACE_VARIANT_DEFAULT
-#define HRT_TRACE_VARIANT_DEFAULT 1
+#define HRT_TRACE_VARIANT_DEFAULT 2
 #endif
 
+// Called by ALL lanes of a wave (uniform control flow); lanes with valid == false carry a dummy
+// ray and their result is meaningless.
 template <int VARIANT, typename TriPtr>
-__device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
+__device__ __forceinline__ Hit closest_hit(TriPtr tri, TriPtr cull, uint32_t num_tri, F3 o, F3 d,
+                                           bool valid, uint32_t lane)
 {
-    if constexpr (VARIANT == 0) return closest_hit_plain(tri, num_tri, o, d);
-    else return closest_hit_staged(tri, num_tri, o, d);
+    if constexpr (VARIANT == 0) {
+        Hit h = {HRT_NO_HIT, 1e9f};
+        if (valid) h = closest_hit_plain(tri, num_tri, o, d);
+        return h;
+    } else if constexpr (VARIANT == 1) {
+        Hit h = {HRT_NO_HIT, 1e9f};
+        if (valid) h = closest_hit_staged(tri, num_tri, o, d);
+        return h;
+    } else {
+        return closest_hit_packet(tri, cull, num_tri, o, d, valid, lane);
+    }
 }
 
 template <typename TriPtr>
@@ -301,7 +507,13 @@ enum : uint32_t {
 };
 enum : uint32_t { R_A0 = 0, R_A1, R_A2, R_A3, R_TAU, R_DX, R_DY, R_DZ, R_DFS };
 
-// LDS image: [num_tri*4 float4 (if staged)] [17*4 float4 materials] [num_rx float4 RX pos]
+__device__ __forceinline__ float *stage_field(const hrt_kparams &P, uint32_t f)
+{
+    return reinterpret_cast<float *>(P.ws + P.off_stage + (uint64_t)f * P.cap * 4u);
+}
+
+// LDS image: [num_tri*4 float4 rows][num_tri float4 cull lengths] (both only if staged)
+//            [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts]
 template <bool TRI_IN_LDS, int VARIANT>
 __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams P,
                                                                const uint32_t b)
@@ -310,17 +522,22 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
     const uint32_t tid = threadIdx.x;
     const bool first = (b == 0);
     const bool do_trace = (b < P.num_bounces);
-    uint32_t *counts = reinterpret_cast<uint32_t *>(P.ws + P.off_counts);
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
     const uint32_t n_in = first ? P.n0 : counts[b];
     if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;   // whole block: nothing to do
 
     const uint32_t T = P.num_tri;
     const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+    const float4 *g_cull = reinterpret_cast<const float4 *>(P.tri_cull);
     float4 *l_tri = lds;
-    float4 *l_mat = lds + (TRI_IN_LDS ? 4u * T : 0u);
+    float4 *l_cull = lds + (TRI_IN_LDS ? 4u * T : 0u);
+    float4 *l_mat = l_cull + (TRI_IN_LDS ? T : 0u);
     float4 *l_rx = l_mat + 4u * HRT_NUM_MATERIALS;
-    if (TRI_IN_LDS)
+    uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(l_rx + P.num_rx);
+    if (TRI_IN_LDS) {
         for (uint32_t k = tid; k < 4u * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
+        for (uint32_t k = tid; k < T; k += HRT_BLOCK) l_cull[k] = g_cull[k];
+    }
     {
         const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
         for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) l_mat[k] = g_mat[k];
@@ -328,13 +545,17 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
     }
     __syncthreads();
-    // the table the loops read: LDS image or (wave-uniform index => scalar loads) global
+    // the tables the loops read: LDS image or (wave-uniform index) global
     auto tri = [&]() {
         if constexpr (TRI_IN_LDS) return (const float4 *)l_tri;
         else return g_tri;
     }();
+    auto cull = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float4 *)l_cull;
+        else return g_cull;
+    }();
 
-    const uint32_t lane = tid & 63u;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
 
     for (uint64_t base = (uint64_t)blockIdx.x * HRT_BLOCK; base < n_in;
          base += (uint64_t)gridDim.x * HRT_BLOCK) {
@@ -348,9 +569,12 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
         float a0 = 1.f, a1 = 0.f, a2 = 1.f, a3 = 0.f;
         if (valid) {
             if (first) {
-                // src/compute_paths.c:452-466 + the launch Doppler term :494-500
-                const uint32_t tx = i / P.num_local, il = i - tx * P.num_local;
-                ray = i;
+                // src/compute_paths.c:452-466 + the launch Doppler term :494-500.  Lane i
+                // takes the i-th ray of the COHERENT launch order (P.order), so that a wave
+                // is a narrow ray packet.
+                const uint32_t tx = i / P.num_local, pos = i - tx * P.num_local;
+                const uint32_t il = P.order ? P.order[pos] : pos;
+                ray = tx * P.num_local + il;
                 o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
                 d = {P.dirs[3 * (uint64_t)il], P.dirs[3 * (uint64_t)il + 1],
                      P.dirs[3 * (uint64_t)il + 2]};
@@ -390,13 +614,14 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
                 mat_alpha = m3.y;
             }
             for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
+                const float4 rp = l_rx[rx];
+                F3 w = sub3({rp.x, rp.y, rp.z}, o);
+                const float d2rx = sqrtf(dot3(w, w));
+                w = {w.x / d2rx, w.y / d2rx, w.z / d2rx};
+                if (!valid) w = {0.f, 0.f, 1.f};
+                const Hit sh = closest_hit<VARIANT>(tri, cull, T, o, w, valid, lane);
                 bool unblocked = false;
                 if (valid) {
-                    const float4 rp = l_rx[rx];
-                    F3 w = sub3({rp.x, rp.y, rp.z}, o);
-                    const float d2rx = sqrtf(dot3(w, w));
-                    w = {w.x / d2rx, w.y / d2rx, w.z / d2rx};
-                    const Hit sh = closest_hit<VARIANT>(tri, T, o, w);
                     if (sh.tri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, sh.tri), w);
                     if (sh.tri != HRT_NO_HIT && sh.t <= 1.f) {
                         rec_field(P, pb, rx, R_A0)[i] = 0.f;
@@ -436,57 +661,115 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             bool hit = false;
             uint32_t ntri = 0;
             float nth = 0.f;
-            if (valid) {
-                const Hit h = closest_hit<VARIANT>(tri, T, o, d);
-                if (h.tri != HRT_NO_HIT) {
-                    hit = true;
-                    ntri = h.tri;
-                    const F3 n = tri_normal(tri, h.tri);
-                    nth = incidence_angle(n, d);
-                    const uint32_t mesh = tri_mesh(tri, h.tri);
-                    const uint32_t mat =
-                        __float_as_uint(reinterpret_cast<const float4 *>(P.mesh)[mesh].w);
-                    float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
-                    float fsl = P.fsl_mult * h.t;
-                    fsl *= fsl;
-                    if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
-                    const float b0 = a0 * R.x - a1 * R.y;
-                    const float b1 = a0 * R.y + a1 * R.x;
-                    const float b2 = a2 * R.z - a3 * R.w;
-                    const float b3 = a2 * R.w + a3 * R.z;
-                    a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-                    tau += h.t / kC;
-                    o = add3(mul3(d, h.t), o);
-                    const float dn = dot3(d, n);
-                    d = sub3(d, mul3(n, 2.f * dn));
-                    o = add3(o, mul3(d, 1e-4f));
-                }
+            const Hit h = closest_hit<VARIANT>(tri, cull, T, o, d, valid, lane);
+            if (valid && h.tri != HRT_NO_HIT) {
+                hit = true;
+                ntri = h.tri;
+                const F3 n = tri_normal(tri, h.tri);
+                nth = incidence_angle(n, d);
+                const uint32_t mesh = tri_mesh(tri, h.tri);
+                const uint32_t mat =
+                    __float_as_uint(reinterpret_cast<const float4 *>(P.mesh)[mesh].w);
+                float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
+                float fsl = P.fsl_mult * h.t;
+                fsl *= fsl;
+                if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
+                const float b0 = a0 * R.x - a1 * R.y;
+                const float b1 = a0 * R.y + a1 * R.x;
+                const float b2 = a2 * R.z - a3 * R.w;
+                const float b3 = a2 * R.w + a3 * R.z;
+                a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                tau += h.t / kC;
+                o = add3(mul3(d, h.t), o);
+                const float dn = dot3(d, n);
+                d = sub3(d, mul3(n, 2.f * dn));
+                o = add3(o, mul3(d, 1e-4f));
             }
-            // stream compaction of the survivors: ballot + prefix count, one atomic per wave
+            // STABLE compaction, step 1: survivors of this 256-ray chunk, in input order, go to
+            // the front of the chunk's slice of the staging block; the chunk's count goes to
+            // chunk_cnt.  hrt_scan_kernel / hrt_move_kernel then concatenate the slices in
+            // chunk order, so the next live list keeps the (coherent) order of this one.
             const unsigned long long m = __ballot(hit);
-            if (m) {
-                uint32_t wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&counts[b + 1], (uint32_t)__popcll(m));
-                wbase = __shfl(wbase, 0);
-                if (hit) {
-                    const uint32_t k = wbase + lane_prefix(m);
-                    hit_field(P, b, H_RAY)[k] = __uint_as_float(ray);
-                    hit_field(P, b, H_TRI)[k] = __uint_as_float(ntri);
-                    hit_field(P, b, H_THETA)[k] = nth;
-                    hit_field(P, b, H_FS0)[k] = fs0;
-                    hit_field(P, b, H_OX)[k] = o.x;
-                    hit_field(P, b, H_OY)[k] = o.y;
-                    hit_field(P, b, H_OZ)[k] = o.z;
-                    hit_field(P, b, H_DX)[k] = d.x;
-                    hit_field(P, b, H_DY)[k] = d.y;
-                    hit_field(P, b, H_DZ)[k] = d.z;
-                    hit_field(P, b, H_A0)[k] = a0;
-                    hit_field(P, b, H_A1)[k] = a1;
-                    hit_field(P, b, H_A2)[k] = a2;
-                    hit_field(P, b, H_A3)[k] = a3;
-                    hit_field(P, b, H_TAU)[k] = tau;
-                }
+            if (lane == 0) l_wcnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) {
+                const uint32_t c = l_wcnt[w];
+                before += (w < wave) ? c : 0u;
+                total += c;
             }
+            __syncthreads();
+            const uint32_t chunk = (uint32_t)(base / HRT_BLOCK);
+            if (tid == 0) reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] = total;
+            if (hit) {
+                const uint64_t k = base + before + lane_prefix(m);
+                stage_field(P, H_RAY)[k] = __uint_as_float(ray);
+                stage_field(P, H_TRI)[k] = __uint_as_float(ntri);
+                stage_field(P, H_THETA)[k] = nth;
+                stage_field(P, H_FS0)[k] = fs0;
+                stage_field(P, H_OX)[k] = o.x;
+                stage_field(P, H_OY)[k] = o.y;
+                stage_field(P, H_OZ)[k] = o.z;
+                stage_field(P, H_DX)[k] = d.x;
+                stage_field(P, H_DY)[k] = d.y;
+                stage_field(P, H_DZ)[k] = d.z;
+                stage_field(P, H_A0)[k] = a0;
+                stage_field(P, H_A1)[k] = a1;
+                stage_field(P, H_A2)[k] = a2;
+                stage_field(P, H_A3)[k] = a3;
+                stage_field(P, H_TAU)[k] = tau;
+            }
+        }
+    }
+}
+
+// STABLE compaction, step 2: exclusive scan of the per-chunk survivor counts of bounce b (one
+// workgroup; at most cap/256 chunks) -> chunk_off[], and the total -> counts[b+1].
+__global__ __launch_bounds__(1024) void hrt_scan_kernel(const hrt_kparams P, const uint32_t b)
+{
+    __shared__ uint32_t part[1024];
+    uint32_t *counts = reinterpret_cast<uint32_t *>(P.ws + P.off_counts);
+    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_cnt);
+    uint32_t *off = reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_off);
+    const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
+    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
+    const uint32_t per = (n_chunks + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_chunks);
+    uint32_t sum = 0;
+    for (uint32_t c = lo; c < hi; ++c) sum += cnt[c];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t s = 1; s < 1024u; s <<= 1) {   // Hillis-Steele inclusive scan
+        const uint32_t v = (threadIdx.x >= s) ? part[threadIdx.x - s] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t c = lo; c < hi; ++c) {
+        off[c] = run;
+        run += cnt[c];
+    }
+    if (threadIdx.x == 1023u) counts[b + 1] = part[1023];
+}
+
+// STABLE compaction, step 3: slice c of the staging block -> hit block b at chunk_off[c].
+__global__ __launch_bounds__(HRT_BLOCK) void hrt_move_kernel(const hrt_kparams P,
+                                                             const uint32_t b)
+{
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_cnt);
+    const uint32_t *off = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_off);
+    const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
+    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t n = cnt[c], dst = off[c];
+        if (threadIdx.x < n) {
+            const uint64_t src = (uint64_t)c * HRT_BLOCK + threadIdx.x;
+#pragma unroll
+            for (uint32_t f = 0; f < 15u; ++f)
+                hit_field(P, b, f)[dst + threadIdx.x] = stage_field(P, f)[src];
         }
     }
 }
@@ -513,7 +796,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
         } else {
             // per-lane triangle loop over the global table (different rays per lane, same
             // triangle index: still wave-uniform addresses)
-            const Hit h = closest_hit<0>(tri, P.num_tri, o, d);
+            const Hit h = closest_hit_plain(tri, P.num_tri, o, d);
             if (h.tri != HRT_NO_HIT && h.t <= 1.f) {
                 status = 1u;   // blocked (:548-554)
             } else {
@@ -554,6 +837,19 @@ __global__ void hrt_selftest_math_kernel(int fn, const float *in, float *out, ui
     }
     }
     out[i] = y;
+}
+
+template <bool LDS, int V>
+static void launch_bounce_t(const hrt_kparams *P, uint32_t bounce, uint32_t blocks, size_t lds,
+                            hipStream_t st, hipError_t *err)
+{
+    if (lds > 64u * 1024u) {
+        *err = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_bounce_kernel<LDS, V>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (*err != hipSuccess) return;
+    }
+    hipLaunchKernelGGL((hrt_bounce_kernel<LDS, V>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P,
+                       bounce);
 }
 
 thread_local char g_err[256];
@@ -604,40 +900,44 @@ int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream)
     uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
     if (blocks > HRT_MAX_GRID) blocks = HRT_MAX_GRID;
     if (blocks == 0) blocks = 1;
-    // HRT_TRACE_VARIANT=0 selects the plain (reference-sequence) intersection loop: kept for
-    // A/B timing and as an in-library cross-check of the staged loop (tests run both)
+    // HRT_TRACE_VARIANT: 2 = packet culling + staged tests (default), 1 = staged tests over all
+    // triangles, 0 = the reference's plain sequence.  All three give bit-identical results;
+    // 0 and 1 are kept for A/B timing and as in-library cross-checks (the GPU tests run all).
     static const int variant = []() {
         const char *v = getenv("HRT_TRACE_VARIANT");
         return (v && *v) ? atoi(v) : HRT_TRACE_VARIANT_DEFAULT;
     }();
-    const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
+    const uint64_t tri_bytes = (uint64_t)P->num_tri * (HRT_TRI_FLOATS + 4u) * 4u;
     const bool in_lds = tri_bytes <= HRT_LDS_TRI_BYTES_MAX;
     const size_t small = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) +
-                         (size_t)P->num_rx * 16u;
+                         (size_t)P->num_rx * 16u + 16u;
+    const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + small;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    const uint32_t nb = (uint32_t)blocks;
     if (in_lds) {
-        const size_t lds = (size_t)tri_bytes + small;
-        if (lds > 64u * 1024u) {
-            const void *fn = variant == 0
-                                 ? reinterpret_cast<const void *>(&hrt_bounce_kernel<true, 0>)
-                                 : reinterpret_cast<const void *>(&hrt_bounce_kernel<true, 1>);
-            const hipError_t e =
-                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        if (variant == 0)
-            hipLaunchKernelGGL((hrt_bounce_kernel<true, 0>), dim3((uint32_t)blocks), dim3(HRT_BLOCK),
-                               lds, (hipStream_t)stream, *P, bounce);
-        else
-            hipLaunchKernelGGL((hrt_bounce_kernel<true, 1>), dim3((uint32_t)blocks), dim3(HRT_BLOCK),
-                               lds, (hipStream_t)stream, *P, bounce);
+        if (variant == 0) launch_bounce_t<true, 0>(P, bounce, nb, lds, st, &err);
+        else if (variant == 1) launch_bounce_t<true, 1>(P, bounce, nb, lds, st, &err);
+        else launch_bounce_t<true, 2>(P, bounce, nb, lds, st, &err);
     } else {
-        if (variant == 0)
-            hipLaunchKernelGGL((hrt_bounce_kernel<false, 0>), dim3((uint32_t)blocks),
-                               dim3(HRT_BLOCK), small, (hipStream_t)stream, *P, bounce);
-        else
-            hipLaunchKernelGGL((hrt_bounce_kernel<false, 1>), dim3((uint32_t)blocks),
-                               dim3(HRT_BLOCK), small, (hipStream_t)stream, *P, bounce);
+        if (variant == 0) launch_bounce_t<false, 0>(P, bounce, nb, lds, st, &err);
+        else if (variant == 1) launch_bounce_t<false, 1>(P, bounce, nb, lds, st, &err);
+        else launch_bounce_t<false, 2>(P, bounce, nb, lds, st, &err);
     }
+    if (err != hipSuccess) return (int)err;
+    return (int)hipGetLastError();
+}
+
+// stable compaction of the survivors of `bounce` (scan of chunk counts, then the move)
+int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream)
+{
+    const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
+    uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
+    if (blocks > HRT_MAX_GRID) blocks = HRT_MAX_GRID;
+    if (blocks == 0) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hrt_scan_kernel, dim3(1), dim3(1024), 0, st, *P, bounce);
+    hipLaunchKernelGGL(hrt_move_kernel, dim3((uint32_t)blocks), dim3(HRT_BLOCK), 0, st, *P, bounce);
     return (int)hipGetLastError();
 }
 

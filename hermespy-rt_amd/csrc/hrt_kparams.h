@@ -23,6 +23,7 @@ extern "C" {
 typedef struct {
     /* scene (device pointers) */
     const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
+    const float *tri_cull;/* [num_tri][4]: |e1|, |e2|, |e2-e1|, |e1 x e2| (packet culling) */
     const float *mesh;    /* [num_mesh][HRT_MESH_FLOATS] */
     const float *mat;     /* [17][HRT_MAT_FLOATS] */
     uint32_t num_tri, num_mesh;
@@ -34,6 +35,7 @@ typedef struct {
     float dop_mult;       /* f / c */
     /* shard */
     const float *dirs;    /* [num_local][3] */
+    const uint32_t *order;/* [num_local] coherent launch order (local ray of position i), or NULL */
     uint32_t num_local;
     uint32_t num_bounces;
     uint32_t n0;          /* num_tx * num_local */
@@ -42,7 +44,7 @@ typedef struct {
     uint8_t *ws;
     uint64_t cap;
     uint64_t off_counts, off_los, off_hits, hit_block_bytes, off_recs, rec_block_bytes,
-        off_masks;
+        off_masks, off_stage, off_chunk_cnt, off_chunk_off;
 } hrt_kparams;
 
 /* ---- the shim (hrt_kernels.hip).  All return 0 or a positive hipError_t. ---- */
@@ -57,6 +59,7 @@ int hrt_hip_stream_sync(void *stream);
 int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
 /* events: opaque handles */
 int hrt_hip_event_create(void **ev);

@@ -21,7 +21,7 @@ from . import lib as _lib
 
 class Tracer:
     def __init__(self, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
-                 num_bounces, rank=0, world=1, chunk=0, device=None, host_threads=0):
+                 num_bounces, rank=0, world=1, chunk=0, device=None, host_threads=0, coherent=True):
         import torch  # torch first: its HIP runtime is the one the library binds to
 
         if not torch.cuda.is_available():
@@ -63,8 +63,19 @@ class Tracer:
             C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)), host_threads),
             "hrt_launch_dirs_host")
         self.dirs_host = dirs
+        # coherent launch order: a wave = a narrow ray packet (speed only; results are keyed
+        # by ray id)
+        self.order_host = None
+        if coherent:
+            order = np.empty(self.num_local, np.uint32)
+            _lib.check(self.L.hrt_launch_order_host(
+                C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)),
+                order.ctypes.data_as(C.POINTER(C.c_uint32))), "hrt_launch_order_host")
+            self.order_host = order
         with torch.cuda.device(self.device):
             self.dirs = torch.from_numpy(dirs).to(self.device)
+            self.order = (torch.from_numpy(self.order_host.view(np.int32)).to(self.device)
+                          if coherent else None)
             self.ws = torch.empty(int(self.layout.total_bytes), dtype=torch.uint8, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
         self.last_times = None
@@ -89,11 +100,13 @@ class Tracer:
         times = _lib.KernelTimes() if timed else None
         _lib.check(self.L.hrt_trace(
             self.problem, C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()),
+            C.c_void_p(self.order.data_ptr()) if self.order is not None else None,
             C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream),
             C.byref(times) if timed else None), "hrt_trace")
         if timed:
             n = int(times.num_bounce_launches)
             self.last_times = (float(times.los_ms), [float(times.bounce_ms[i]) for i in range(n)])
+            self.last_compact_ms = [float(times.compact_ms[i]) for i in range(n)]
             return self.last_times
         return None
 

@@ -16,7 +16,7 @@ EXPORTED = (
     "hrt_version", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
-    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_layout_query", "hrt_trace",
+    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_layout_query", "hrt_trace",
     "hrt_work_from_counts", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
     "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
     "hrt_selftest_math",
@@ -36,12 +36,12 @@ class Shard(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "total_bytes", "cap", "off_counts", "off_los", "off_hits", "hit_block_bytes",
-        "off_recs", "rec_block_bytes", "off_masks")]
+        "off_recs", "rec_block_bytes", "off_masks", "off_stage", "off_chunk_cnt", "off_chunk_off")]
 
 
 class KernelTimes(C.Structure):
     _fields_ = [("los_ms", C.c_float), ("bounce_ms", C.c_float * 33),
-                ("num_bounce_launches", C.c_uint32)]
+                ("compact_ms", C.c_float * 33), ("num_bounce_launches", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -108,7 +108,9 @@ def load():
     L.hrt_launch_dirs_host.restype = C.c_int
     L.hrt_layout_query.argtypes = [vp, C.POINTER(Shard), C.POINTER(Layout)]
     L.hrt_layout_query.restype = C.c_int
-    L.hrt_trace.argtypes = [vp, C.POINTER(Shard), vp, vp, u64, vp, C.POINTER(KernelTimes)]
+    L.hrt_launch_order_host.argtypes = [C.POINTER(Shard), f32p, C.POINTER(u32)]
+    L.hrt_launch_order_host.restype = C.c_int
+    L.hrt_trace.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, C.POINTER(KernelTimes)]
     L.hrt_trace.restype = C.c_int
     L.hrt_work_from_counts.argtypes = [vp, C.POINTER(Shard), C.POINTER(u32), C.POINTER(Stats)]
     L.hrt_work_from_counts.restype = None

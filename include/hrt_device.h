@@ -68,6 +68,14 @@ uint64_t hrt_shard_global_path(const hrt_shard *s, uint64_t local_i);
  * cores. */
 int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads);
 
+/* Coherent launch order of this shard: a permutation of 0..num_local-1 (order[i] = local ray
+ * launched by lane i) that walks the sphere in z-bands, serpentine in azimuth, so that 64
+ * consecutive lanes -- one wavefront -- form a narrow ray packet (what the packet culling of
+ * the bounce kernel feeds on).  Pure function of `dirs` ([num_local][3], from
+ * hrt_launch_dirs_host).  Results do not depend on the order (records carry ray ids); only
+ * speed does. */
+int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order_out);
+
 /* ---- workspace layout ----
  * cap = num_tx * num_local rounded up to 256 entries.  Every array below holds `cap`
  * elements of 4 bytes unless noted, so a field is a contiguous, coalesced run.
@@ -76,8 +84,8 @@ int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads);
  *                                      = live rays entering bounce b; counts[0] = ntx*nloc
  *   los         num_rx*num_tx entries of HRT_LOS_FLOATS floats
  *   hit block b (b = 0 .. num_bounces-1), fields HRT_HIT_*:
- *       the rays that hit something at bounce b, in arbitrary (wave-granular) order, with
- *       their state AFTER the bounce.  It is also the live list of bounce b+1.
+ *       the rays that hit something at bounce b, in the (stable) order of the live list they
+ *       came from, with their state AFTER the bounce.  It is also the live list of bounce b+1.
  *   rec block b: for rx in 0..num_rx-1, fields HRT_REC_*: the scatter record of
  *       (hit i of block b, rx) at element i; plus one bit per (rx, i) "unblocked".
  *       A blocked record has a_* = tau = 0 and its dir/dfs elements are not written.
@@ -117,6 +125,8 @@ typedef struct {
                                                        + (rx*HRT_REC_FIELDS + f)*cap*4 */
     uint64_t rec_block_bytes;
     uint64_t off_masks;         /* u64 words of (b, rx) at off_masks + (b*num_rx + rx)*(cap/64)*8 */
+    /* scratch of the stable compaction (one hit block of staging, per-chunk counts/offsets) */
+    uint64_t off_stage, off_chunk_cnt, off_chunk_off;
 } hrt_layout;
 
 int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
@@ -125,16 +135,21 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
 typedef struct {
     float los_ms;
     float bounce_ms[33];        /* launch b of the bounce kernel, b = 0 .. num_bounces */
+    float compact_ms[33];       /* scan + move kernels after launch b (0 for the last) */
     uint32_t num_bounce_launches;
 } hrt_kernel_times;
 
 /* Enqueue the whole path on `stream`: zero the counters, LoS kernel, then num_bounces + 1
  * launches of the bounce kernel (launch b scatters the hits of bounce b-1 to every RX and
- * traces bounce b).  Asynchronous unless `times` != NULL, in which case HIP events are
- * recorded around every launch on `stream` and the call returns after the stream drained.
- * d_dirs: device [num_local][3] floats (this shard's launch directions). */
-int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs, void *d_workspace,
-              uint64_t workspace_bytes, void *stream, hrt_kernel_times *times);
+ * traces bounce b), each trace followed by the two tiny kernels of the stable compaction.
+ * Asynchronous unless `times` != NULL, in which case HIP events are recorded around every
+ * launch on `stream` and the call returns after the stream drained.
+ * d_dirs:  device [num_local][3] floats (this shard's launch directions).
+ * d_order: device [num_local] u32 coherent launch order (hrt_launch_order_host), or NULL for
+ *          index order (same results, less coherent packets). */
+int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+              const uint32_t *d_order, void *d_workspace, uint64_t workspace_bytes, void *stream,
+              hrt_kernel_times *times);
 
 /* Algorithmic work of a finished trace from its (host copy of) counts: see hrt_stats. */
 void hrt_work_from_counts(const hrt_problem *p, const hrt_shard *s, const uint32_t *counts,
