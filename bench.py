@@ -248,6 +248,15 @@ def main():
                     trace_variant=os.environ.get("HRT_TRACE_VARIANT", "default(2: packet culling)"),
                     note="VALU-bound intersection work, not HBM-bound: see DESIGN.md section 6")
 
+    kstats = None
+    try:
+        import ctypes
+        from hermespy_rt_amd import lib as _l2
+        arr = (ctypes.c_uint64 * 24)()
+        if _l2.load().hrt_debug_kernel_stats(local_rank, arr, 0) == 0 and any(arr):
+            kstats = [[int(arr[k * 8 + j]) for j in range(6)] for k in range(3)]
+    except Exception:
+        pass
     if rank == 0:
         out = dict(
             metric="resolved propagation paths/sec", value=paths * args.steps / dt,
@@ -262,6 +271,8 @@ def main():
             nonzero_paths_per_sec=(unblk + nrx * ntx) * args.steps / dt,
             work=dict(live=live, records=records, records_unblocked=unblk, tests=tests),
             roofline=roofline)
+        if kstats:
+            out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
         print(json.dumps(out), flush=True)

@@ -546,3 +546,14 @@ int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t 
     hrt_device_free(device, d_out);
     return rc;
 }
+
+/* Diagnostic counters of the packet-culling loop (all zero unless built with `make STATS=1`):
+ * out[kind][8], kind 0 = primary traces of launch 0, 1 = primary traces of later launches,
+ * 2 = shadow traces; columns: wave-traces, usable packets, candidate triangles, staged bodies
+ * reaching stage 2, stage 3, the exact divisions. */
+int hrt_debug_kernel_stats(int device, uint64_t *out24, int reset)
+{
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    HRT_HIP(hrt_hip_read_stats((unsigned long long *)out24, reset), "hrt_hip_read_stats");
+    return HRT_OK;
+}

@@ -196,43 +196,93 @@ __device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, uint32_t num_tri, 
 // |edge| * ro.  sigma is the same for all rays iff the cone does not straddle the plane
 // (|N| (|ax.n| cos(alpha) - sin(alpha)) > 2 E_d); otherwise the triangle is kept.  Tolerances
 // are doubled and a 1e-4 relative slack covers |d| != 1 and the roundoff of this test itself.
+// Diagnostic counters (built only with -DHRT_KERNEL_STATS, `make STATS=1`): per kind of trace
+// (0 primary of launch 0, 1 primary of later launches, 2 shadow): wave-traces, usable packets,
+// candidate triangles, staged bodies that reached stage 2 / 3 / the exact divisions.
+#ifdef HRT_KERNEL_STATS
+__device__ unsigned long long g_stats[3][8];
+#define HRT_STAT(kind, idx, val)                                                      \
+    do {                                                                              \
+        if (lane == 0) atomicAdd(&g_stats[kind][idx], (unsigned long long)(val));     \
+    } while (0)
+#else
+#define HRT_STAT(kind, idx, val) do { } while (0)
+#endif
+
+// Wave-wide reductions on the VALU only (DPP row shifts + row broadcasts, the GCN/CDNA
+// reduction idiom): 6 DPP ops, no LDS traffic, result read from lane 63 into an SGPR, i.e.
+// wave-uniform.  All 64 lanes must be active (callers run in uniform control flow).
+#define HRT_DPP(old_, src_, ctrl_, rowmask_)                                                     \
+    __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(old_),           \
+                                                          (int)__float_as_uint(src_), ctrl_,    \
+                                                          rowmask_, 0xf, false))
+struct OpMin { static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+struct OpAdd { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, const float ident)
+{
+    v = Op::f(v, HRT_DPP(ident, v, 0x111, 0xf));   // row_shr:1
+    v = Op::f(v, HRT_DPP(ident, v, 0x112, 0xf));   // row_shr:2
+    v = Op::f(v, HRT_DPP(ident, v, 0x114, 0xf));   // row_shr:4
+    v = Op::f(v, HRT_DPP(ident, v, 0x118, 0xf));   // row_shr:8   -> lane 15 of each row: row total
+    v = Op::f(v, HRT_DPP(ident, v, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
+    v = Op::f(v, HRT_DPP(ident, v, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ float wave_min_f(float v) { return wave_reduce<OpMin>(v, 3.0e38f); }
+__device__ __forceinline__ float wave_max_f(float v) { return wave_reduce<OpMax>(v, -3.0e38f); }
+__device__ __forceinline__ float wave_sum_f(float v) { return wave_reduce<OpAdd>(v, 0.f); }
+
+struct Ball { F3 c; float r; bool ok; };   // bounding ball of the packet's ray origins
+
 struct Packet {
-    F3 oc, ax;
-    float ro, cosa, sina;
+    F3 oc;      // a point every ray LINE of the packet passes within `ro` of
+    float ro;
+    F3 bc;      // bounding ball of the actual ray origins (behind test, |s| bound)
+    float br;
+    F3 ax;      // direction cone
+    float cosa, sina;
     bool usable;
 };
 
-__device__ __forceinline__ float wave_min_f(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ float wave_sum_f(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-
 // must be called by ALL lanes of the wave (valid = lane carries a real ray)
-__device__ __noinline__ Packet packet_bounds(F3 o, F3 d, bool valid)
+__device__ __forceinline__ Ball origin_ball(F3 o, bool valid)
 {
     const float big = 3.0e38f;
-    Packet P;
     const float lox = wave_min_f(valid ? o.x : big), hix = wave_max_f(valid ? o.x : -big);
     const float loy = wave_min_f(valid ? o.y : big), hiy = wave_max_f(valid ? o.y : -big);
     const float loz = wave_min_f(valid ? o.z : big), hiz = wave_max_f(valid ? o.z : -big);
-    P.oc = {0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz)};
+    Ball B;
+    B.c = {0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz)};
     const F3 ext = {hix - lox, hiy - loy, hiz - loz};
     // half diagonal of the bounding box, rounded up
-    P.ro = 0.5f * sqrtf(dot3(ext, ext)) * 1.00001f + 1e-6f * (fabsf(P.oc.x) + fabsf(P.oc.y) + fabsf(P.oc.z));
+    B.r = 0.5f * sqrtf(dot3(ext, ext)) * 1.00001f +
+          1e-6f * (fabsf(B.c.x) + fabsf(B.c.y) + fabsf(B.c.z));
+    B.ok = lox <= hix;
+    return B;
+}
+
+// Direction cone of the packet.  `apex` != nullptr: every ray was aimed at that point (shadow
+// rays towards an RX): numerators Nu, Nv, Nu+Nv-det and det are invariants of the ray LINE,
+// and the line of a ray built as normalise(apex - o) passes within 4u*L of apex (componentwise
+// rounding of the subtraction and the division), so the edge tests use the apex as the common
+// line point with that tiny radius instead of the origins' bounding ball.
+__device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid, const F3 *apex)
+{
+    Packet P;
+    P.bc = B.c;
+    P.br = B.r;
+    if (apex) {
+        P.oc = *apex;
+        const F3 v = sub3(*apex, B.c);
+        const float lmax = sqrtf(dot3(v, v)) * 1.00001f + B.r;
+        P.ro = 8.f * (0.5f * kEps) * lmax + 1e-7f;
+    } else {
+        P.oc = B.c;
+        P.ro = B.r;
+    }
     const F3 sd = {wave_sum_f(valid ? d.x : 0.f), wave_sum_f(valid ? d.y : 0.f),
                    wave_sum_f(valid ? d.z : 0.f)};
     const float n2 = dot3(sd, sd);
@@ -243,16 +293,24 @@ __device__ __noinline__ Packet packet_bounds(F3 o, F3 d, bool valid)
     P.cosa = c;
     P.sina = sqrtf(fmaxf(0.f, 1.f - c * c));
     // wide packets (half-angle > ~60 deg) or degenerate axis: culling cannot pay
-    P.usable = (n2 > 1e-12f) && (c > 0.5f) && (lox <= hix);
+    P.usable = (n2 > 1e-12f) && (c > 0.5f) && B.ok;
     return P;
 }
 
-// upper / lower bound of d.G over the cone (|d| = 1), G given with its norm
+// The culling test needs conservative bounds, not exact values: it uses the single-instruction
+// approximate v_sqrt_f32 / v_rsq_f32 (1 ulp) instead of the IEEE-correct expansions (~15
+// instructions each); their error is far inside the 1e-4 relative slack added below.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// upper / lower bound of d.G over the cone (|d| = 1)
 __device__ __forceinline__ void cone_range(const Packet &P, F3 G, float &lo, float &hi)
 {
-    const float g = sqrtf(dot3(G, G));
-    const float c = (g > 0.f) ? dot3(P.ax, G) / g : 0.f;
-    const float s = sqrtf(fmaxf(0.f, 1.f - c * c));
+    const float g2 = dot3(G, G);
+    const float ig = (g2 > 1e-30f) ? fast_rsq(g2) : 0.f;
+    const float g = g2 * ig;
+    const float c = fminf(1.f, fmaxf(-1.f, dot3(P.ax, G) * ig));
+    const float s = fast_sqrt(fmaxf(0.f, 1.f - c * c));
     hi = (c >= P.cosa) ? g : g * (c * P.cosa + s * P.sina);
     lo = (c <= -P.cosa) ? -g : g * (c * P.cosa - s * P.sina);
     const float slack = 1e-4f * g;
@@ -270,8 +328,9 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const F3 e1 = {q0.w, q1.x, q1.y};
     const F3 e2 = {q1.z, q1.w, q2.x};
     const F3 nh = {q2.y, q2.z, q2.w};
+    const F3 sb = sub3(P.bc, v1);
+    const float S = fast_sqrt(dot3(sb, sb)) * 1.0001f + P.br;
     const F3 sc = sub3(P.oc, v1);
-    const float S = sqrtf(dot3(sc, sc)) * 1.00001f + P.ro;
     const float Ed = kE * L.x * L.y;
     const float dn = dot3(P.ax, nh);
     // all rays on one side of the plane's direction field, so sigma is constant
@@ -283,9 +342,9 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const float tol_v = 2.f * (2.f * kEps * aN + Ev);
     const float tol_w = 2.f * (4.f * kEps * aN + Eu + Ev + Ed);
     // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - ro, h + ro]
-    const float h = dot3(sc, nh);
-    const float snt_max = pos ? (h + P.ro) : -(h - P.ro);   // divided by |N|
-    bool cull = snt_max * L.w < -2.f * Et - 1e-4f * L.w * (fabsf(h) + P.ro);
+    const float h = dot3(sb, nh);
+    const float snt_max = pos ? (h + P.br) : -(h - P.br);   // divided by |N|
+    bool cull = snt_max * L.w < -2.f * Et - 1e-4f * L.w * (fabsf(h) + P.br);
     const F3 Gu = cross3(e2, sc);
     const F3 Gv = cross3(sc, e1);
     const F3 Nn = cross3(e1, e2);
@@ -317,15 +376,18 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
         const float k1a = kK1 * a, k2a = kK2 * a;                                               \
         bool rej = !valid | (a < kEps) | (nu_s < -k1a) | (nu_s > k2a);                          \
         if (!wave_all(rej)) {                                                                   \
+            HRT_STAT(kind, 3, 1);                                                               \
             const F3 q = cross3(s, e1);                                                         \
             const float nv = dot3(d, q);                                                        \
             const float nv_s = xor_sign(nv, sg);                                                \
             rej |= (nv_s < -k1a) | ((nu_s + nv_s) > kK3 * a);                                   \
             if (!wave_all(rej)) {                                                               \
+                HRT_STAT(kind, 4, 1);                                                           \
                 const float nt = dot3(e2, q);                                                   \
                 const float nt_s = xor_sign(nt, sg);                                            \
                 rej |= (nt_s < kK5 * a) | (nt_s > (best * a) * kK2);                            \
                 if (!wave_all(rej)) {                                                           \
+                    HRT_STAT(kind, 5, 1);                                                       \
                     const float u = nu / det;                                                   \
                     const float v = nv / det;                                                   \
                     const float w = u + v;                                                      \
@@ -343,12 +405,17 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 // ALL lanes of the wave must call this (uniform control flow); invalid lanes carry dummies.
 template <typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, TriPtr cull, uint32_t num_tri,
-                                                  F3 o, F3 d, bool valid, uint32_t lane)
+                                                  F3 o, F3 d, bool valid, uint32_t lane,
+                                                  const Ball &B, const F3 *apex,
+                                                  [[maybe_unused]] int kind)
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
-    const Packet P = packet_bounds(o, d, valid);
+    const Packet P = packet_bounds(B, d, valid, apex);
+    HRT_STAT(kind, 0, 1);
+    HRT_STAT(kind, 1, P.usable ? 1 : 0);
     if (!P.usable) {
+        HRT_STAT(kind, 2, num_tri);
         for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
         return {who, best};
     }
@@ -358,6 +425,7 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, TriPtr cull, uint3
         if (jl < num_tri)
             cand = !packet_culls(P, tri[4 * jl], tri[4 * jl + 1], tri[4 * jl + 2], cull[jl]);
         unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        HRT_STAT(kind, 2, __popcll(m));
         while (m) {   // ascending triangle index: the reference's tie-break order
             const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
@@ -375,7 +443,8 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, TriPtr cull, uint3
 // ray and their result is meaningless.
 template <int VARIANT, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit(TriPtr tri, TriPtr cull, uint32_t num_tri, F3 o, F3 d,
-                                           bool valid, uint32_t lane)
+                                           bool valid, uint32_t lane, const Ball &B,
+                                           const F3 *apex, int kind)
 {
     if constexpr (VARIANT == 0) {
         Hit h = {HRT_NO_HIT, 1e9f};
@@ -386,7 +455,7 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TriPtr cull, uint32_t num
         if (valid) h = closest_hit_staged(tri, num_tri, o, d);
         return h;
     } else {
-        return closest_hit_packet(tri, cull, num_tri, o, d, valid, lane);
+        return closest_hit_packet(tri, cull, num_tri, o, d, valid, lane, B, apex, kind);
     }
 }
 
@@ -598,6 +667,11 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             }
         }
 
+        // bounding ball of this wave's ray origins: shared by the num_rx shadow traces and the
+        // primary trace of this iteration (the origin does not change until the reflection)
+        Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
+        if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
+
         // ---- scatter the hits of bounce b-1 to every RX, in RX order, carrying theta
         //      (src/compute_paths.c:671-723; quirks Q6, Q7, Q8) ----
         if (!first) {
@@ -619,7 +693,8 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
                 const float d2rx = sqrtf(dot3(w, w));
                 w = {w.x / d2rx, w.y / d2rx, w.z / d2rx};
                 if (!valid) w = {0.f, 0.f, 1.f};
-                const Hit sh = closest_hit<VARIANT>(tri, cull, T, o, w, valid, lane);
+                const F3 apex = {rp.x, rp.y, rp.z};
+                const Hit sh = closest_hit<VARIANT>(tri, cull, T, o, w, valid, lane, ball, &apex, 2);
                 bool unblocked = false;
                 if (valid) {
                     if (sh.tri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, sh.tri), w);
@@ -661,7 +736,8 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             bool hit = false;
             uint32_t ntri = 0;
             float nth = 0.f;
-            const Hit h = closest_hit<VARIANT>(tri, cull, T, o, d, valid, lane);
+            const Hit h = closest_hit<VARIANT>(tri, cull, T, o, d, valid, lane, ball, nullptr,
+                                               first ? 0 : 1);
             if (valid && h.tri != HRT_NO_HIT) {
                 hit = true;
                 ntri = h.tri;
@@ -947,6 +1023,23 @@ int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, v
     hipLaunchKernelGGL(hrt_selftest_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, fn, d_in, d_out, n);
     return (int)hipGetLastError();
+}
+
+int hrt_hip_read_stats(unsigned long long *out24, int reset)
+{
+#ifdef HRT_KERNEL_STATS
+    hipError_t e = hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 24);
+    if (e != hipSuccess) return (int)e;
+    if (reset) {
+        unsigned long long z[24] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z);
+    }
+    return (int)e;
+#else
+    (void)reset;
+    for (int i = 0; i < 24; ++i) out24[i] = 0;
+    return 0;
+#endif
 }
 
 int hrt_hip_event_create(void **ev)

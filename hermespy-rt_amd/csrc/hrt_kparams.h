@@ -61,6 +61,7 @@ int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
+int hrt_hip_read_stats(unsigned long long *out24, int reset);
 /* events: opaque handles */
 int hrt_hip_event_create(void **ev);
 int hrt_hip_event_destroy(void *ev);

@@ -171,6 +171,12 @@ int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
  * ((float)acos((double)x) folded to [0, pi/2]).  Tests compare the result with the host libm. */
 int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t n);
 
+/* Diagnostic counters of the packet-culling loop; all zero unless the library was built with
+ * `make STATS=1`.  out24 = [3 kinds][8]: kind 0 primary traces of launch 0, 1 primary traces
+ * of later launches, 2 shadow traces; columns: wave-traces, usable packets, candidate
+ * triangles, staged bodies reaching stage 2, stage 3, the exact divisions, -, -. */
+int hrt_debug_kernel_stats(int device, uint64_t *out24, int reset);
+
 #ifdef __cplusplus
 }
 #endif
