@@ -186,13 +186,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    bounce_ms, los_ms, compact_ms = [], [], []
+    bounce_ms, los_ms, compact_ms, shade_ms = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lm, bm = step(True)   # HIP events around every launch, on the launch stream
         los_ms.append(lm)
         bounce_ms.append(bm)
         compact_ms.append(sum(tr.last_compact_ms))
+        shade_ms.append(tr.last_shade_ms)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -220,8 +221,12 @@ def main():
     records, tests, unblk, live = tot[0], tot[1] + nrx * ntx * tr.num_tri, tot[2], tot[3:]
     paths = records + nrx * ntx
 
-    # ---- roofline of the dominant kernel (hrt_bounce_kernel), rank 0's launches ----
-    bm = np.asarray(bounce_ms, dtype=np.float64)          # [steps, nb+1]
+    # ---- roofline of the dominant kernels, rank 0's launches.  One launch of "the bounce" is
+    # the pair hrt_trace_kernel (intersection) + hrt_shade_kernel (records, Fresnel, reflect):
+    # the algorithmic bytes of SURVEY 8(d) are those of the pair, so is the duration. ----
+    tm = np.asarray(bounce_ms, dtype=np.float64)          # [steps, nb+1] trace kernel
+    sm = np.asarray(shade_ms, dtype=np.float64)           # [steps, nb+1] shade kernel
+    bm = tm + sm
     kern_ms_step = float(bm.sum(axis=1).mean())
     n_launch = bm.shape[1]
     unb_local = unblocked
@@ -238,11 +243,14 @@ def main():
             traffic_src = pj[args.workload]["source"]
     except (OSError, ValueError, KeyError):
         pass
-    roofline = dict(bound="hbm", kernel="hrt_bounce_kernel", achieved=ach, peak=HBM_PEAK_GBS,
+    roofline = dict(bound="hbm", kernel="hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)",
+                    achieved=ach, peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=B_local / n_launch,
                     avg_launch_ms=kern_ms_step / n_launch, launches_per_step=n_launch,
                     per_launch_ms=[float(x) for x in bm.mean(axis=0)],
+                    trace_kernel_ms=[float(x) for x in tm.mean(axis=0)],
+                    shade_kernel_ms=[float(x) for x in sm.mean(axis=0)],
                     kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
                     compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
                     trace_variant=os.environ.get("HRT_TRACE_VARIANT", "default(2: packet culling)"),

@@ -224,6 +224,10 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
 
         t0 = hrt_now_s();
         DL(w.h_counts, L.off_counts, (nb + 2) * 4);
+        if (w.h_counts[nb + 1] != 0) {
+            rc = hrt_fail(HRT_E_HIP, "device reported internal error flags %u", w.h_counts[nb + 1]);
+            goto done;
+        }
         {
             hrt_stats bs;
             hrt_work_from_counts(prob, &s, w.h_counts, &bs);

@@ -36,14 +36,13 @@ struct hrt_problem {
     float f_ghz, fsl_mult, dop_mult;
     /* host copies */
     float *h_tri;       /* [num_tri][HRT_TRI_FLOATS] */
-    float *h_cull;      /* [num_tri][4] |e1| |e2| |e2-e1| |e1 x e2| */
     float *h_mesh;      /* [num_mesh][HRT_MESH_FLOATS] */
     float *h_mat;       /* [17][HRT_MAT_FLOATS] */
     uint32_t *h_tri_mesh, *h_tri_face;
     hrt_eta eta[HRT_NUM_MATERIALS];
     /* one device allocation holding everything */
     void *d_blob;
-    const float *d_tri, *d_cull, *d_mesh, *d_mat, *d_rx_pos, *d_tx_pos, *d_rx_vel, *d_tx_vel;
+    const float *d_tri, *d_mesh, *d_mat, *d_rx_pos, *d_tx_pos, *d_rx_vel, *d_tx_vel;
 };
 
 /* error plumbing: set the thread's last-error text and return `code` */

@@ -71,7 +71,7 @@ void hrt_problem_destroy(hrt_problem *p)
         hrt_hip_set_device(p->device);
         hrt_hip_free(p->d_blob);
     }
-    free(p->h_tri); free(p->h_cull); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
+    free(p->h_tri); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
     free(p);
 }
 
@@ -115,12 +115,11 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
     p->dop_mult = f_hz / HRT_C_F;
 
     p->h_tri = (float *)calloc((size_t)(T ? T : 1) * HRT_TRI_FLOATS, sizeof(float));
-    p->h_cull = (float *)calloc((size_t)(T ? T : 1) * 4, sizeof(float));
     p->h_mesh = (float *)calloc((size_t)p->num_mesh * HRT_MESH_FLOATS, sizeof(float));
     p->h_mat = (float *)calloc(HRT_NUM_MATERIALS * HRT_MAT_FLOATS, sizeof(float));
     p->h_tri_mesh = (uint32_t *)malloc((size_t)(T ? T : 1) * sizeof(uint32_t));
     p->h_tri_face = (uint32_t *)malloc((size_t)(T ? T : 1) * sizeof(uint32_t));
-    if (!p->h_cull || !p->h_tri || !p->h_mesh || !p->h_mat || !p->h_tri_mesh || !p->h_tri_face) {
+    if (!p->h_tri || !p->h_mesh || !p->h_mat || !p->h_tri_mesh || !p->h_tri_face) {
         hrt_problem_destroy(p);
         return hrt_fail(HRT_E_NOMEM, "out of host memory");
     }
@@ -145,7 +144,7 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
             {
                 Vec3 e3 = v_sub(e2, e1);
                 Vec3 c = {e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x};
-                float *cr = p->h_cull + (size_t)j * 4;
+                float *cr = row + 16;
                 cr[0] = sqrtf(e1.x * e1.x + e1.y * e1.y + e1.z * e1.z) * 1.000001f;
                 cr[1] = sqrtf(e2.x * e2.x + e2.y * e2.y + e2.z * e2.z) * 1.000001f;
                 cr[2] = sqrtf(e3.x * e3.x + e3.y * e3.y + e3.z * e3.z) * 1.000001f;
@@ -168,11 +167,10 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
 
     /* one device blob: tri | mesh | mat | rx_pos | tx_pos | rx_vel | tx_vel (256-B aligned) */
     uint64_t sz_tri = round_up((uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4, 256);
-    uint64_t sz_cull = round_up((uint64_t)(T ? T : 1) * 16, 256);
     uint64_t sz_mesh = round_up((uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4, 256);
     uint64_t sz_mat = round_up(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4, 256);
     uint64_t sz_rx = round_up((uint64_t)num_rx * 12, 256), sz_tx = round_up((uint64_t)num_tx * 12, 256);
-    uint64_t total = sz_tri + sz_cull + sz_mesh + sz_mat + 2 * sz_rx + 2 * sz_tx;
+    uint64_t total = sz_tri + sz_mesh + sz_mat + 2 * sz_rx + 2 * sz_tx;
     int rc;
     if ((rc = hrt_hip_set_device(device)) != 0) {
         hrt_problem_destroy(p);
@@ -185,7 +183,6 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
     }
     uint8_t *b = (uint8_t *)p->d_blob;
     p->d_tri = (const float *)b; b += sz_tri;
-    p->d_cull = (const float *)b; b += sz_cull;
     p->d_mesh = (const float *)b; b += sz_mesh;
     p->d_mat = (const float *)b; b += sz_mat;
     p->d_rx_pos = (const float *)b; b += sz_rx;
@@ -193,7 +190,6 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
     p->d_rx_vel = (const float *)b; b += sz_rx;
     p->d_tx_vel = (const float *)b;
     if ((rc = hrt_hip_h2d((void *)p->d_tri, p->h_tri, (uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4)) ||
-        (rc = hrt_hip_h2d((void *)p->d_cull, p->h_cull, (uint64_t)(T ? T : 1) * 16)) ||
         (rc = hrt_hip_h2d((void *)p->d_mesh, p->h_mesh, (uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4)) ||
         (rc = hrt_hip_h2d((void *)p->d_mat, p->h_mat, HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4)) ||
         (rc = hrt_hip_h2d((void *)p->d_rx_pos, rx_pos, (uint64_t)num_rx * 12)) ||
@@ -386,6 +382,7 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     L->off_stage = off;  off += L->hit_block_bytes;
     L->off_chunk_cnt = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
     L->off_chunk_off = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
+    L->off_res = off;    off += ((uint64_t)p->num_rx + 1) * 2 * cap * 4;
     L->total_bytes = off;
     return HRT_OK;
 }
@@ -406,7 +403,7 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
 
     hrt_kparams K;
     memset(&K, 0, sizeof K);
-    K.tri = p->d_tri; K.tri_cull = p->d_cull; K.mesh = p->d_mesh; K.mat = p->d_mat;
+    K.tri = p->d_tri; K.mesh = p->d_mesh; K.mat = p->d_mat;
     K.num_tri = p->num_tri; K.num_mesh = p->num_mesh;
     K.rx_pos = p->d_rx_pos; K.tx_pos = p->d_tx_pos; K.rx_vel = p->d_rx_vel; K.tx_vel = p->d_tx_vel;
     K.num_rx = p->num_rx; K.num_tx = p->num_tx;
@@ -422,13 +419,14 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
     K.hit_block_bytes = L.hit_block_bytes; K.off_recs = L.off_recs;
     K.rec_block_bytes = L.rec_block_bytes; K.off_masks = L.off_masks;
     K.off_stage = L.off_stage; K.off_chunk_cnt = L.off_chunk_cnt; K.off_chunk_off = L.off_chunk_off;
+    K.off_res = L.off_res;
 
     HRT_HIP(hrt_hip_set_device(p->device), "hipSetDevice");
     const uint32_t nb = s->num_bounces;
-    /* events: [0,1] around LoS; per launch b: start, end of trace (= start of compaction),
-     * end of compaction */
-    void *ev[2 + 3 * 34] = {0};
-    const uint32_t n_ev = times ? 2 + 3 * (nb + 1) : 0;
+    /* events: [0,1] around LoS; per launch b: start, end of trace (= start of shade), end of
+     * shade (= start of compaction), end of compaction */
+    void *ev[2 + 4 * 34] = {0};
+    const uint32_t n_ev = times ? 2 + 4 * (nb + 1) : 0;
     for (uint32_t i = 0; i < n_ev; ++i) {
         rc = hrt_hip_event_create(&ev[i]);
         if (rc) {
@@ -443,19 +441,22 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
     STEP(hrt_hip_launch_los(&K, stream));
     if (times) STEP(hrt_hip_event_record(ev[1], stream));
     for (uint32_t b = 0; b <= nb; ++b) {
-        if (times) STEP(hrt_hip_event_record(ev[2 + 3 * b], stream));
-        STEP(hrt_hip_launch_bounce(&K, b, stream));
-        if (times) STEP(hrt_hip_event_record(ev[3 + 3 * b], stream));
+        if (times) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
+        STEP(hrt_hip_launch_trace(&K, b, stream));
+        if (times) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
+        STEP(hrt_hip_launch_shade(&K, b, stream));
+        if (times) STEP(hrt_hip_event_record(ev[4 + 4 * b], stream));
         if (b < nb) STEP(hrt_hip_launch_compact(&K, b, stream));
-        if (times) STEP(hrt_hip_event_record(ev[4 + 3 * b], stream));
+        if (times) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
     }
     if (times && !hip) {
         STEP(hrt_hip_stream_sync(stream));
         memset(times, 0, sizeof *times);
         if (!hip) STEP(hrt_hip_event_elapsed_ms(ev[0], ev[1], &times->los_ms));
         for (uint32_t b = 0; b <= nb && !hip; ++b) {
-            STEP(hrt_hip_event_elapsed_ms(ev[2 + 3 * b], ev[3 + 3 * b], &times->bounce_ms[b]));
-            STEP(hrt_hip_event_elapsed_ms(ev[3 + 3 * b], ev[4 + 3 * b], &times->compact_ms[b]));
+            STEP(hrt_hip_event_elapsed_ms(ev[2 + 4 * b], ev[3 + 4 * b], &times->trace_ms[b]));
+            STEP(hrt_hip_event_elapsed_ms(ev[3 + 4 * b], ev[4 + 4 * b], &times->shade_ms[b]));
+            STEP(hrt_hip_event_elapsed_ms(ev[4 + 4 * b], ev[5 + 4 * b], &times->compact_ms[b]));
         }
         times->num_bounce_launches = nb + 1;
     }

@@ -6,8 +6,9 @@
 //   incidence_angle    src/compute_paths.c:281-283
 //   fresnel            src/compute_paths.c:300-344  refl_coefs (ITU-R P.2040-3 eq. 31a/31b)
 //   scatter_pattern    src/compute_paths.c:359-415  scat_coefs
-//   hrt_bounce_kernel  src/compute_paths.c:460-466 (state init), :596-723 (one bounce:
-//                      trace, Fresnel, FSL, reflect, scatter to every RX)
+//   hrt_trace_kernel   the moeller_trumbore calls of :615 and :682 (all traces of a launch)
+//   hrt_shade_kernel   src/compute_paths.c:460-466 (state init), :616-664 (Fresnel, FSL,
+//                      reflect), :671-723 (scatter records)
 //   hrt_los_kernel     src/compute_paths.c:515-577
 //
 // Design (MI355X-first, not the reference's loop nest):
@@ -65,6 +66,13 @@ __device__ __forceinline__ F3 cross3(F3 a, F3 b)
 
 struct Hit { uint32_t tri; float t; };
 
+// One triangle = HRT_ROW float4 (80 bytes): v1.xyz e1.x | e1.yz e2.xy | e2.z n.xyz | mesh - - - |
+// |e1| |e2| |e2-e1| |e1 x e2|.  80 B is deliberate: when the 64 lanes of a wave each read the
+// row of a DIFFERENT triangle (packet culling), the 16-lane groups of a ds_read_b128 start at
+// banks 20*l mod 64 -- 16 distinct multiples of 4 -- so the gather is conflict-free (a 64-byte
+// row gives 4-way conflicts: 76 % of all LDS cycles before the change).
+constexpr uint32_t HRT_ROW = HRT_TRI_FLOATS / 4;
+
 // Closest hit over the whole triangle table, lowest index wins ties (strict '<').
 // `tri` points at LDS (broadcast reads) or at global memory (wave-uniform loads).
 //
@@ -76,7 +84,7 @@ __device__ __forceinline__ Hit closest_hit_plain(TriPtr tri, uint32_t num_tri, F
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
     for (uint32_t j = 0; j < num_tri; ++j) {
-        const float4 q0 = tri[4 * j], q1 = tri[4 * j + 1], q2 = tri[4 * j + 2];
+        const float4 q0 = tri[HRT_ROW * j], q1 = tri[HRT_ROW * j + 1], q2 = tri[HRT_ROW * j + 2];
         const F3 v1 = {q0.x, q0.y, q0.z};
         const F3 e1 = {q0.w, q1.x, q1.y};
         const F3 e2 = {q1.z, q1.w, q2.x};
@@ -136,7 +144,7 @@ __device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, uint32_t num_tri, 
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
     for (uint32_t j = 0; j < num_tri; ++j) {
-        const float4 q0 = tri[4 * j], q1 = tri[4 * j + 1], q2 = tri[4 * j + 2];
+        const float4 q0 = tri[HRT_ROW * j], q1 = tri[HRT_ROW * j + 1], q2 = tri[HRT_ROW * j + 2];
         const F3 v1 = {q0.x, q0.y, q0.z};
         const F3 e1 = {q0.w, q1.x, q1.y};
         const F3 e2 = {q1.z, q1.w, q2.x};
@@ -362,7 +370,7 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 // one staged test of triangle j for every lane; `rej0` lanes do not participate
 #define HRT_STAGED_BODY(J)                                                                      \
     {                                                                                           \
-        const float4 q0 = tri[4 * (J)], q1 = tri[4 * (J) + 1], q2 = tri[4 * (J) + 2];           \
+        const float4 q0 = tri[HRT_ROW * (J)], q1 = tri[HRT_ROW * (J) + 1], q2 = tri[HRT_ROW * (J) + 2];           \
         const F3 v1 = {q0.x, q0.y, q0.z};                                                       \
         const F3 e1 = {q0.w, q1.x, q1.y};                                                       \
         const F3 e2 = {q1.z, q1.w, q2.x};                                                       \
@@ -403,35 +411,55 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     }
 
 // ALL lanes of the wave must call this (uniform control flow); invalid lanes carry dummies.
+// Two phases per block of up to 16 rounds (1024 triangles): first every round is culled and
+// its candidate mask parked in this wave's LDS slots, THEN the candidates are walked -- so the
+// packet description and the culling temporaries are dead while the intersection tests run
+// (and vice versa), which is what keeps the kernel's register allocation low.
+constexpr uint32_t kMaskRounds = 16;
+
 template <typename TriPtr>
-__device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, TriPtr cull, uint32_t num_tri,
-                                                  F3 o, F3 d, bool valid, uint32_t lane,
-                                                  const Ball &B, const F3 *apex,
+__device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, F3 o, F3 d,
+                                                  bool valid, uint32_t lane, const Ball &B,
+                                                  const F3 *apex, unsigned long long *wmask,
                                                   [[maybe_unused]] int kind)
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
-    const Packet P = packet_bounds(B, d, valid, apex);
-    HRT_STAT(kind, 0, 1);
-    HRT_STAT(kind, 1, P.usable ? 1 : 0);
-    if (!P.usable) {
-        HRT_STAT(kind, 2, num_tri);
-        for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
-        return {who, best};
+    {
+        const Packet P = packet_bounds(B, d, valid, apex);
+        HRT_STAT(kind, 0, 1);
+        HRT_STAT(kind, 1, P.usable ? 1 : 0);
+        if (!P.usable) {
+            HRT_STAT(kind, 2, num_tri);
+            for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
+            return {who, best};
+        }
+        for (uint32_t base = 0, r = 0; base < num_tri && r < kMaskRounds; base += 64u, ++r) {
+            const uint32_t jl = base + lane;
+            bool cand = false;
+            if (jl < num_tri)
+                cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
+                                     tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 4]);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+            HRT_STAT(kind, 2, __popcll(m));
+            if (lane == 0) wmask[r] = m;
+        }
     }
-    for (uint32_t base = 0; base < num_tri; base += 64u) {
-        const uint32_t jl = base + lane;
-        bool cand = false;
-        if (jl < num_tri)
-            cand = !packet_culls(P, tri[4 * jl], tri[4 * jl + 1], tri[4 * jl + 2], cull[jl]);
-        unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
-        HRT_STAT(kind, 2, __popcll(m));
+    for (uint32_t base = 0, r = 0; base < num_tri && r < kMaskRounds; base += 64u, ++r) {
+        // written by this wave's lane 0 above, read back by all its lanes: same wave, in order
+        unsigned long long m = wmask[r];
+        // (the builtin returns int: widen through uint32_t or the low word sign-extends)
+        const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+        const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+        m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
         while (m) {   // ascending triangle index: the reference's tie-break order
             const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
             HRT_STAGED_BODY(j)
         }
     }
+    // scenes beyond kMaskRounds*64 triangles: the rest is tested without culling
+    for (uint32_t j = kMaskRounds * 64u; j < num_tri; ++j) HRT_STAGED_BODY(j)
     return {who, best};
 }
 
@@ -442,9 +470,9 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, TriPtr cull, uint3
 // Called by ALL lanes of a wave (uniform control flow); lanes with valid == false carry a dummy
 // ray and their result is meaningless.
 template <int VARIANT, typename TriPtr>
-__device__ __forceinline__ Hit closest_hit(TriPtr tri, TriPtr cull, uint32_t num_tri, F3 o, F3 d,
-                                           bool valid, uint32_t lane, const Ball &B,
-                                           const F3 *apex, int kind)
+__device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F3 d, bool valid,
+                                           uint32_t lane, const Ball &B, const F3 *apex,
+                                           unsigned long long *wmask, int kind)
 {
     if constexpr (VARIANT == 0) {
         Hit h = {HRT_NO_HIT, 1e9f};
@@ -455,21 +483,21 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TriPtr cull, uint32_t num
         if (valid) h = closest_hit_staged(tri, num_tri, o, d);
         return h;
     } else {
-        return closest_hit_packet(tri, cull, num_tri, o, d, valid, lane, B, apex, kind);
+        return closest_hit_packet(tri, num_tri, o, d, valid, lane, B, apex, wmask, kind);
     }
 }
 
 template <typename TriPtr>
 __device__ __forceinline__ F3 tri_normal(TriPtr tri, uint32_t j)
 {
-    const float4 q2 = tri[4 * j + 2];
+    const float4 q2 = tri[HRT_ROW * j + 2];
     return {q2.y, q2.z, q2.w};
 }
 
 template <typename TriPtr>
 __device__ __forceinline__ uint32_t tri_mesh(TriPtr tri, uint32_t j)
 {
-    return __float_as_uint(tri[4 * j + 3].x);
+    return __float_as_uint(tri[HRT_ROW * j + 3].x);
 }
 
 // acos in double of the float dot product, stored to float, folded to [0, pi/2] with the
@@ -580,12 +608,135 @@ __device__ __forceinline__ float *stage_field(const hrt_kparams &P, uint32_t f)
 {
     return reinterpret_cast<float *>(P.ws + P.off_stage + (uint64_t)f * P.cap * 4u);
 }
+// result of trace k of live-list entry i: closest triangle (or HRT_NO_HIT) and its distance
+__device__ __forceinline__ uint32_t *res_tri(const hrt_kparams &P, uint32_t k)
+{
+    return reinterpret_cast<uint32_t *>(P.ws + P.off_res + (uint64_t)(2u * k) * P.cap * 4u);
+}
+__device__ __forceinline__ float *res_t(const hrt_kparams &P, uint32_t k)
+{
+    return reinterpret_cast<float *>(P.ws + P.off_res + (uint64_t)(2u * k + 1u) * P.cap * 4u);
+}
 
-// LDS image: [num_tri*4 float4 rows][num_tri float4 cull lengths] (both only if staged)
-//            [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts]
+// src/compute_paths.c:452-455 -- ray i of the launch set.  Lane i takes the i-th ray of the
+// COHERENT launch order (P.order), so that a wave is a narrow ray packet.
+__device__ __forceinline__ void launch_ray(const hrt_kparams &P, uint32_t i, uint32_t &ray, F3 &o,
+                                           F3 &d, uint32_t &tx)
+{
+    tx = i / P.num_local;
+    const uint32_t pos = i - tx * P.num_local;
+    const uint32_t il = P.order ? P.order[pos] : pos;
+    ray = tx * P.num_local + il;
+    o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
+    d = {P.dirs[3 * (uint64_t)il], P.dirs[3 * (uint64_t)il + 1], P.dirs[3 * (uint64_t)il + 2]};
+}
+
+// shadow ray from o towards rx (src/compute_paths.c:676-678): direction and distance
+__device__ __forceinline__ F3 shadow_dir(F3 o, F3 rx, float &d2rx)
+{
+    F3 w = sub3(rx, o);
+    d2rx = sqrtf(dot3(w, w));
+    return {w.x / d2rx, w.y / d2rx, w.z / d2rx};
+}
+
+// ===================================================================================
+// TRACE kernel: pure geometry.  Launch b owes, for every entry i of the live list (the rays
+// that hit at bounce b-1; at b = 0 the launch set), num_rx shadow traces (b >= 1) and one
+// primary trace (b < num_bounces).  A work unit is (chunk of 256 entries, trace kind k); a
+// workgroup walks units, a wave does ONE trace per unit for 64 rays: it needs only the ray
+// origin/direction, so the register footprint is small and the occupancy high.  Results
+// (closest triangle, distance) go to res_tri/res_t[k][i]; all shading is the SHADE kernel's.
+// LDS image: [num_tri*5 float4 rows (if staged)][num_rx RX pos][4 waves x 16 u64 masks]
+// ===================================================================================
+#ifndef HRT_TRACE_WAVES_PER_SIMD
+#define HRT_TRACE_WAVES_PER_SIMD 1
+#endif
 template <bool TRI_IN_LDS, int VARIANT>
-__global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams P,
-                                                               const uint32_t b)
+__global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace_kernel(
+    const hrt_kparams P, const uint32_t b)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t tid = threadIdx.x;
+    const bool first = (b == 0);
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    const uint32_t n_in = first ? P.n0 : counts[b];
+    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
+    // trace kinds of this launch: shadow rays to rx 0..num_rx-1 (k = rx), primary (k = num_rx)
+    const uint32_t k_lo = first ? P.num_rx : 0u;
+    const uint32_t k_hi = (b < P.num_bounces) ? P.num_rx + 1u : P.num_rx;
+    const uint32_t kinds = k_hi - k_lo;
+    const uint64_t n_units = (uint64_t)n_chunks * kinds;
+    if (blockIdx.x >= n_units) return;
+
+    const uint32_t T = P.num_tri;
+    const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+    float4 *l_tri = lds;
+    float4 *l_rx = lds + (TRI_IN_LDS ? HRT_ROW * T : 0u);
+    unsigned long long *l_mask = reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
+                                 (tid >> 6) * kMaskRounds;
+    if (TRI_IN_LDS)
+        for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
+    for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
+        l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
+    __syncthreads();
+    auto tri = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float4 *)l_tri;
+        else return g_tri;
+    }();
+    const uint32_t lane = tid & 63u;
+
+    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t chunk = (uint32_t)(unit / kinds);
+        const uint32_t k = k_lo + (uint32_t)(unit - (uint64_t)chunk * kinds);
+        const uint32_t i = chunk * HRT_BLOCK + tid;
+        const bool valid = i < n_in;
+        F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
+        if (valid) {
+            if (first) {
+                uint32_t ray, tx;
+                launch_ray(P, i, ray, o, d, tx);
+            } else {
+                const uint32_t pb = b - 1;
+                o = {hit_field(P, pb, H_OX)[i], hit_field(P, pb, H_OY)[i],
+                     hit_field(P, pb, H_OZ)[i]};
+                if (k == P.num_rx)
+                    d = {hit_field(P, pb, H_DX)[i], hit_field(P, pb, H_DY)[i],
+                         hit_field(P, pb, H_DZ)[i]};
+            }
+        }
+        const bool shadow = k < P.num_rx;
+        F3 apex = {0.f, 0.f, 0.f};
+        if (shadow) {
+            const float4 rp = l_rx[k];
+            apex = {rp.x, rp.y, rp.z};
+            float d2rx;
+            const F3 w = shadow_dir(o, apex, d2rx);
+            if (valid) d = w;
+        }
+        Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
+        if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
+        const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball,
+                                           shadow ? &apex : nullptr, l_mask,
+                                           shadow ? 2 : (first ? 0 : 1));
+        if (valid) {
+            res_tri(P, k)[i] = h.tri;
+            res_t(P, k)[i] = h.t;
+        }
+    }
+}
+
+// ===================================================================================
+// SHADE kernel: everything that is per ray and not intersection -- a streaming kernel.
+// For entry i of the live list of launch b:
+//   (b >= 1) scatter records of bounce b-1 for every RX IN ORDER, carrying theta through the
+//            shadow results (src/compute_paths.c:671-723; quirks Q6, Q7, Q8);
+//   (b < nb) the bounce itself: incidence angle, Fresnel, FSL, delay, reflect (:611-659), and
+//            step 1 of the stable compaction (survivors of the 256-entry chunk to the front
+//            of the chunk's slice of the staging block, count to chunk_cnt).
+// LDS: [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts]
+// ===================================================================================
+__global__ __launch_bounds__(HRT_BLOCK) void hrt_shade_kernel(const hrt_kparams P,
+                                                              const uint32_t b)
 {
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -593,20 +744,12 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
     const bool do_trace = (b < P.num_bounces);
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
     const uint32_t n_in = first ? P.n0 : counts[b];
-    if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;   // whole block: nothing to do
+    if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;
 
-    const uint32_t T = P.num_tri;
-    const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
-    const float4 *g_cull = reinterpret_cast<const float4 *>(P.tri_cull);
-    float4 *l_tri = lds;
-    float4 *l_cull = lds + (TRI_IN_LDS ? 4u * T : 0u);
-    float4 *l_mat = l_cull + (TRI_IN_LDS ? T : 0u);
+    const float4 *tri = reinterpret_cast<const float4 *>(P.tri);   // per-lane rows: global/L2
+    float4 *l_mat = lds;
     float4 *l_rx = l_mat + 4u * HRT_NUM_MATERIALS;
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(l_rx + P.num_rx);
-    if (TRI_IN_LDS) {
-        for (uint32_t k = tid; k < 4u * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
-        for (uint32_t k = tid; k < T; k += HRT_BLOCK) l_cull[k] = g_cull[k];
-    }
     {
         const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
         for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) l_mat[k] = g_mat[k];
@@ -614,16 +757,6 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
     }
     __syncthreads();
-    // the tables the loops read: LDS image or (wave-uniform index) global
-    auto tri = [&]() {
-        if constexpr (TRI_IN_LDS) return (const float4 *)l_tri;
-        else return g_tri;
-    }();
-    auto cull = [&]() {
-        if constexpr (TRI_IN_LDS) return (const float4 *)l_cull;
-        else return g_cull;
-    }();
-
     const uint32_t lane = tid & 63u, wave = tid >> 6;
 
     for (uint64_t base = (uint64_t)blockIdx.x * HRT_BLOCK; base < n_in;
@@ -638,15 +771,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
         float a0 = 1.f, a1 = 0.f, a2 = 1.f, a3 = 0.f;
         if (valid) {
             if (first) {
-                // src/compute_paths.c:452-466 + the launch Doppler term :494-500.  Lane i
-                // takes the i-th ray of the COHERENT launch order (P.order), so that a wave
-                // is a narrow ray packet.
-                const uint32_t tx = i / P.num_local, pos = i - tx * P.num_local;
-                const uint32_t il = P.order ? P.order[pos] : pos;
-                ray = tx * P.num_local + il;
-                o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
-                d = {P.dirs[3 * (uint64_t)il], P.dirs[3 * (uint64_t)il + 1],
-                     P.dirs[3 * (uint64_t)il + 2]};
+                // src/compute_paths.c:452-466 + the launch Doppler term :494-500
+                uint32_t tx;
+                launch_ray(P, i, ray, o, d, tx);
                 const F3 tv = {P.tx_vel[3 * tx], P.tx_vel[3 * tx + 1], P.tx_vel[3 * tx + 2]};
                 fs0 = dot3(tv, d) * P.dop_mult;
             } else {
@@ -667,13 +794,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             }
         }
 
-        // bounding ball of this wave's ray origins: shared by the num_rx shadow traces and the
-        // primary trace of this iteration (the origin does not change until the reflection)
-        Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
-        if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
-
-        // ---- scatter the hits of bounce b-1 to every RX, in RX order, carrying theta
-        //      (src/compute_paths.c:671-723; quirks Q6, Q7, Q8) ----
+        // ---- scatter records of bounce b-1 ----
         if (!first) {
             const uint32_t pb = b - 1;
             F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
@@ -688,17 +809,19 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
                 mat_alpha = m3.y;
             }
             for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
-                const float4 rp = l_rx[rx];
-                F3 w = sub3({rp.x, rp.y, rp.z}, o);
-                const float d2rx = sqrtf(dot3(w, w));
-                w = {w.x / d2rx, w.y / d2rx, w.z / d2rx};
-                if (!valid) w = {0.f, 0.f, 1.f};
-                const F3 apex = {rp.x, rp.y, rp.z};
-                const Hit sh = closest_hit<VARIANT>(tri, cull, T, o, w, valid, lane, ball, &apex, 2);
                 bool unblocked = false;
                 if (valid) {
-                    if (sh.tri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, sh.tri), w);
-                    if (sh.tri != HRT_NO_HIT && sh.t <= 1.f) {
+                    const float4 rp = l_rx[rx];
+                    float d2rx;
+                    const F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
+                    uint32_t stri = res_tri(P, rx)[i];
+                    const float st = res_t(P, rx)[i];
+                    if (stri != HRT_NO_HIT && stri >= P.num_tri) {   // cannot happen; never fault
+                        atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
+                        stri = HRT_NO_HIT;
+                    }
+                    if (stri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, stri), w);
+                    if (stri != HRT_NO_HIT && st <= 1.f) {
                         rec_field(P, pb, rx, R_A0)[i] = 0.f;
                         rec_field(P, pb, rx, R_A1)[i] = 0.f;
                         rec_field(P, pb, rx, R_A2)[i] = 0.f;
@@ -731,35 +854,41 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_bounce_kernel(const hrt_kparams
             }
         }
 
-        // ---- trace bounce b (src/compute_paths.c:611-659) ----
+        // ---- the bounce (src/compute_paths.c:611-659) ----
         if (do_trace) {
             bool hit = false;
             uint32_t ntri = 0;
             float nth = 0.f;
-            const Hit h = closest_hit<VARIANT>(tri, cull, T, o, d, valid, lane, ball, nullptr,
-                                               first ? 0 : 1);
-            if (valid && h.tri != HRT_NO_HIT) {
-                hit = true;
-                ntri = h.tri;
-                const F3 n = tri_normal(tri, h.tri);
-                nth = incidence_angle(n, d);
-                const uint32_t mesh = tri_mesh(tri, h.tri);
-                const uint32_t mat =
-                    __float_as_uint(reinterpret_cast<const float4 *>(P.mesh)[mesh].w);
-                float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
-                float fsl = P.fsl_mult * h.t;
-                fsl *= fsl;
-                if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
-                const float b0 = a0 * R.x - a1 * R.y;
-                const float b1 = a0 * R.y + a1 * R.x;
-                const float b2 = a2 * R.z - a3 * R.w;
-                const float b3 = a2 * R.w + a3 * R.z;
-                a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-                tau += h.t / kC;
-                o = add3(mul3(d, h.t), o);
-                const float dn = dot3(d, n);
-                d = sub3(d, mul3(n, 2.f * dn));
-                o = add3(o, mul3(d, 1e-4f));
+            if (valid) {
+                uint32_t ptri = res_tri(P, P.num_rx)[i];
+                if (ptri != HRT_NO_HIT && ptri >= P.num_tri) {       // cannot happen; never fault
+                    atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 2u);
+                    ptri = HRT_NO_HIT;
+                }
+                if (ptri != HRT_NO_HIT) {
+                    const float pt = res_t(P, P.num_rx)[i];
+                    hit = true;
+                    ntri = ptri;
+                    const F3 n = tri_normal(tri, ptri);
+                    nth = incidence_angle(n, d);
+                    const uint32_t mesh = tri_mesh(tri, ptri);
+                    const uint32_t mat =
+                        __float_as_uint(reinterpret_cast<const float4 *>(P.mesh)[mesh].w);
+                    float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
+                    float fsl = P.fsl_mult * pt;
+                    fsl *= fsl;
+                    if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
+                    const float b0 = a0 * R.x - a1 * R.y;
+                    const float b1 = a0 * R.y + a1 * R.x;
+                    const float b2 = a2 * R.z - a3 * R.w;
+                    const float b3 = a2 * R.w + a3 * R.z;
+                    a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                    tau += pt / kC;
+                    o = add3(mul3(d, pt), o);
+                    const float dn = dot3(d, n);
+                    d = sub3(d, mul3(n, 2.f * dn));
+                    o = add3(o, mul3(d, 1e-4f));
+                }
             }
             // STABLE compaction, step 1: survivors of this 256-ray chunk, in input order, go to
             // the front of the chunk's slice of the staging block; the chunk's count goes to
@@ -916,15 +1045,15 @@ __global__ void hrt_selftest_math_kernel(int fn, const float *in, float *out, ui
 }
 
 template <bool LDS, int V>
-static void launch_bounce_t(const hrt_kparams *P, uint32_t bounce, uint32_t blocks, size_t lds,
-                            hipStream_t st, hipError_t *err)
+static void launch_trace_t(const hrt_kparams *P, uint32_t bounce, uint32_t blocks, size_t lds,
+                           hipStream_t st, hipError_t *err)
 {
     if (lds > 64u * 1024u) {
-        *err = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_bounce_kernel<LDS, V>),
+        *err = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_trace_kernel<LDS, V>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (*err != hipSuccess) return;
     }
-    hipLaunchKernelGGL((hrt_bounce_kernel<LDS, V>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P,
+    hipLaunchKernelGGL((hrt_trace_kernel<LDS, V>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P,
                        bounce);
 }
 
@@ -969,38 +1098,57 @@ int hrt_hip_launch_los(const hrt_kparams *P, void *stream)
     return (int)hipGetLastError();
 }
 
-int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream)
+static uint64_t env_u64(const char *name, uint64_t dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? (uint64_t)atoll(v) : dflt;
+}
+
+// geometry of launch `bounce`: the trace kernel (all shadow + primary traces of the live list)
+int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
 {
     // Shapes are validated by the host (hrt_trace); here only the launch geometry.
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
-    uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
-    if (blocks > HRT_MAX_GRID) blocks = HRT_MAX_GRID;
+    const uint64_t kinds = (bounce == 0) ? 1u : (bounce < P->num_bounces ? P->num_rx + 1u : P->num_rx);
+    uint64_t blocks = ((n_max + HRT_BLOCK - 1) / HRT_BLOCK) * kinds;
+    static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
+    if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
     // HRT_TRACE_VARIANT: 2 = packet culling + staged tests (default), 1 = staged tests over all
     // triangles, 0 = the reference's plain sequence.  All three give bit-identical results;
     // 0 and 1 are kept for A/B timing and as in-library cross-checks (the GPU tests run all).
-    static const int variant = []() {
-        const char *v = getenv("HRT_TRACE_VARIANT");
-        return (v && *v) ? atoi(v) : HRT_TRACE_VARIANT_DEFAULT;
-    }();
-    const uint64_t tri_bytes = (uint64_t)P->num_tri * (HRT_TRI_FLOATS + 4u) * 4u;
+    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
+    const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
     const bool in_lds = tri_bytes <= HRT_LDS_TRI_BYTES_MAX;
-    const size_t small = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) +
-                         (size_t)P->num_rx * 16u + 16u;
-    const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + small;
+    const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
+                       (HRT_BLOCK / 64u) * kMaskRounds * 8u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
     if (in_lds) {
-        if (variant == 0) launch_bounce_t<true, 0>(P, bounce, nb, lds, st, &err);
-        else if (variant == 1) launch_bounce_t<true, 1>(P, bounce, nb, lds, st, &err);
-        else launch_bounce_t<true, 2>(P, bounce, nb, lds, st, &err);
+        if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
+        else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
+        else launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
     } else {
-        if (variant == 0) launch_bounce_t<false, 0>(P, bounce, nb, lds, st, &err);
-        else if (variant == 1) launch_bounce_t<false, 1>(P, bounce, nb, lds, st, &err);
-        else launch_bounce_t<false, 2>(P, bounce, nb, lds, st, &err);
+        if (variant == 0) launch_trace_t<false, 0>(P, bounce, nb, lds, st, &err);
+        else if (variant == 1) launch_trace_t<false, 1>(P, bounce, nb, lds, st, &err);
+        else launch_trace_t<false, 2>(P, bounce, nb, lds, st, &err);
     }
     if (err != hipSuccess) return (int)err;
+    return (int)hipGetLastError();
+}
+
+// shading of launch `bounce`: records of bounce-1, the bounce itself, compaction step 1
+int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
+{
+    const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
+    uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
+    static const uint64_t max_grid = env_u64("HRT_SHADE_GRID", HRT_SHADE_GRID);
+    if (blocks > max_grid) blocks = max_grid;
+    if (blocks == 0) blocks = 1;
+    const size_t lds = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)P->num_rx * 16u + 16u;
+    hipLaunchKernelGGL(hrt_shade_kernel, dim3((uint32_t)blocks), dim3(HRT_BLOCK), lds,
+                       (hipStream_t)stream, *P, bounce);
     return (int)hipGetLastError();
 }
 
@@ -1009,7 +1157,7 @@ int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream)
 {
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
     uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
-    if (blocks > HRT_MAX_GRID) blocks = HRT_MAX_GRID;
+    if (blocks > HRT_SHADE_GRID) blocks = HRT_SHADE_GRID;
     if (blocks == 0) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hrt_scan_kernel, dim3(1), dim3(1024), 0, st, *P, bounce);

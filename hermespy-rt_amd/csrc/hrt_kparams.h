@@ -11,11 +11,12 @@ extern "C" {
 
 #define HRT_NO_HIT 0xFFFFFFFFu
 #define HRT_NUM_MATERIALS 17
-#define HRT_TRI_FLOATS 16  /* v1(3) e1(3) e2(3) n(3) mesh_id(u32) pad(3) */
+#define HRT_TRI_FLOATS 20  /* v1(3) e1(3) e2(3) n(3) mesh_id(u32) pad(3) |e1| |e2| |e2-e1| |e1xe2| */
 #define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */
 #define HRT_MESH_FLOATS 4  /* velocity(3), material_index(u32) */
 #define HRT_BLOCK 256
-#define HRT_MAX_GRID 2048
+#define HRT_TRACE_GRID 8192   /* persistent workgroups of the trace kernel */
+#define HRT_SHADE_GRID 16384
 /* triangle tables up to this many bytes are staged in LDS (160 KiB per CU on gfx950, minus
  * the material/endpoint tables); larger scenes read the table through the scalar cache. */
 #define HRT_LDS_TRI_BYTES_MAX (144u * 1024u)
@@ -23,7 +24,6 @@ extern "C" {
 typedef struct {
     /* scene (device pointers) */
     const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
-    const float *tri_cull;/* [num_tri][4]: |e1|, |e2|, |e2-e1|, |e1 x e2| (packet culling) */
     const float *mesh;    /* [num_mesh][HRT_MESH_FLOATS] */
     const float *mat;     /* [17][HRT_MAT_FLOATS] */
     uint32_t num_tri, num_mesh;
@@ -44,7 +44,7 @@ typedef struct {
     uint8_t *ws;
     uint64_t cap;
     uint64_t off_counts, off_los, off_hits, hit_block_bytes, off_recs, rec_block_bytes,
-        off_masks, off_stage, off_chunk_cnt, off_chunk_off;
+        off_masks, off_stage, off_chunk_cnt, off_chunk_off, off_res;
 } hrt_kparams;
 
 /* ---- the shim (hrt_kernels.hip).  All return 0 or a positive hipError_t. ---- */
@@ -58,7 +58,8 @@ int hrt_hip_memset_async(void *dst, int value, uint64_t bytes, void *stream);
 int hrt_hip_stream_sync(void *stream);
 int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
-int hrt_hip_launch_bounce(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
 int hrt_hip_read_stats(unsigned long long *out24, int reset);

@@ -94,7 +94,8 @@ class Tracer:
     # ------------------------------------------------------------------ run
     def trace(self, timed=False):
         """Enqueue the whole path on torch's current stream.  timed=True records HIP events
-        around every launch on that stream, waits, and returns (los_ms, [bounce_ms...])."""
+        around every launch on that stream, waits, and returns (los_ms, [trace_ms per launch]);
+        shade / compaction times are in last_shade_ms / last_compact_ms."""
         torch = self.torch
         stream = torch.cuda.current_stream(self.device).cuda_stream
         times = _lib.KernelTimes() if timed else None
@@ -105,7 +106,8 @@ class Tracer:
             C.byref(times) if timed else None), "hrt_trace")
         if timed:
             n = int(times.num_bounce_launches)
-            self.last_times = (float(times.los_ms), [float(times.bounce_ms[i]) for i in range(n)])
+            self.last_times = (float(times.los_ms), [float(times.trace_ms[i]) for i in range(n)])
+            self.last_shade_ms = [float(times.shade_ms[i]) for i in range(n)]
             self.last_compact_ms = [float(times.compact_ms[i]) for i in range(n)]
             return self.last_times
         return None
@@ -120,6 +122,8 @@ class Tracer:
         c = self._view(int(self.layout.off_counts), self.nb + 2, torch.int32).cpu().numpy()
         c = c.astype(np.int64) & 0xFFFFFFFF
         c[0] = self.ntx * self.num_local
+        if c[self.nb + 1] != 0:   # set by the shade kernel if a trace result was out of range
+            raise _lib.HrtError("device reported an internal error flag %d" % int(c[self.nb + 1]))
         return c
 
     def los(self):

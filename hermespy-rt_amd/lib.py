@@ -36,11 +36,11 @@ class Shard(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "total_bytes", "cap", "off_counts", "off_los", "off_hits", "hit_block_bytes",
-        "off_recs", "rec_block_bytes", "off_masks", "off_stage", "off_chunk_cnt", "off_chunk_off")]
+        "off_recs", "rec_block_bytes", "off_masks", "off_stage", "off_chunk_cnt", "off_chunk_off", "off_res")]
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("los_ms", C.c_float), ("bounce_ms", C.c_float * 33),
+    _fields_ = [("los_ms", C.c_float), ("trace_ms", C.c_float * 33), ("shade_ms", C.c_float * 33),
                 ("compact_ms", C.c_float * 33), ("num_bounce_launches", C.c_uint32)]
 
 

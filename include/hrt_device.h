@@ -81,7 +81,8 @@ int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order
  * elements of 4 bytes unless noted, so a field is a contiguous, coalesced run.
  *
  *   counts      u32[num_bounces + 2]   counts[b] (b >= 1) = rays that hit at bounce b-1
- *                                      = live rays entering bounce b; counts[0] = ntx*nloc
+ *                                      = live rays entering bounce b; counts[0] unused;
+ *                                      counts[num_bounces+1] = internal error flags (0)
  *   los         num_rx*num_tx entries of HRT_LOS_FLOATS floats
  *   hit block b (b = 0 .. num_bounces-1), fields HRT_HIT_*:
  *       the rays that hit something at bounce b, in the (stable) order of the live list they
@@ -127,6 +128,9 @@ typedef struct {
     uint64_t off_masks;         /* u64 words of (b, rx) at off_masks + (b*num_rx + rx)*(cap/64)*8 */
     /* scratch of the stable compaction (one hit block of staging, per-chunk counts/offsets) */
     uint64_t off_stage, off_chunk_cnt, off_chunk_off;
+    /* trace results of one launch: for trace kind k (0..num_rx-1 shadow to rx k, num_rx the
+     * bounce itself) u32 triangle[cap] then f32 distance[cap] at off_res + (2k, 2k+1)*cap*4 */
+    uint64_t off_res;
 } hrt_layout;
 
 int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
@@ -134,14 +138,16 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
 /* Per-launch device times of one hrt_trace call, filled only when requested. */
 typedef struct {
     float los_ms;
-    float bounce_ms[33];        /* launch b of the bounce kernel, b = 0 .. num_bounces */
+    float trace_ms[33];         /* trace kernel (all intersection work) of launch b = 0..num_bounces */
+    float shade_ms[33];         /* shade kernel (records, Fresnel, reflect) of launch b */
     float compact_ms[33];       /* scan + move kernels after launch b (0 for the last) */
     uint32_t num_bounce_launches;
 } hrt_kernel_times;
 
 /* Enqueue the whole path on `stream`: zero the counters, LoS kernel, then num_bounces + 1
- * launches of the bounce kernel (launch b scatters the hits of bounce b-1 to every RX and
- * traces bounce b), each trace followed by the two tiny kernels of the stable compaction.
+ * launches; launch b = trace kernel (the num_rx shadow rays of every hit of bounce b-1 and the
+ * rays of bounce b: intersection only) + shade kernel (scatter records of bounce b-1; Fresnel,
+ * delay, reflection of bounce b) + the two small kernels of the stable compaction.
  * Asynchronous unless `times` != NULL, in which case HIP events are recorded around every
  * launch on `stream` and the call returns after the stream drained.
  * d_dirs:  device [num_local][3] floats (this shard's launch directions).
