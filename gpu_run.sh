@@ -1,8 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export HRT_BENCH_REHEARSE=1
-timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 3 --steps 3 --warmup 1 --workload c2 > gpurun_out/rehearse3.json 2> gpurun_out/rehearse3.err || (tail -40 gpurun_out/rehearse3.err; exit 1)
-cat gpurun_out/rehearse3.json
-timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 2 --warmup 1 --gather-in-step > gpurun_out/rehearse2.json 2> gpurun_out/rehearse2.err || (tail -40 gpurun_out/rehearse2.err; exit 1)
-cat gpurun_out/rehearse2.json
+export TMPDIR=/tmp
+rm -rf gpurun_out/prof_r01
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err || (tail -30 gpurun_out/bench_prof.err; exit 1)
+bash profiles/collect_pmc.sh r01
+python bench.py --dropin > gpurun_out/dropin_c3.json
+cat gpurun_out/dropin_c3.json

@@ -216,6 +216,8 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         }
         t0 = hrt_now_s();
         if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
+        st.t_launch_dirs_s += hrt_now_s() - t0;   /* host-side launch preparation */
+        t0 = hrt_now_s();
         if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;
         if ((rc = hrt_device_upload(w.device, w.d_order, w.h_order, n_loc * 4))) goto done;
         if ((rc = hrt_trace(prob, &s, (const float *)w.d_dirs, (const uint32_t *)w.d_order, w.d_ws, L.total_bytes, NULL, NULL))) goto done;

@@ -323,20 +323,21 @@ int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads)
 }
 
 /* Coherent launch order: z-bands of about sqrt(n/128) rows, serpentine in azimuth, so 64
- * consecutive positions are a roughly square patch of the sphere. */
-static int cmp_u64(const void *a, const void *b)
-{
-    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
-    return (x > y) - (x < y);
-}
-
+ * consecutive positions are a roughly square patch of the sphere.  Keys are 32 bits (12 bits of
+ * band, 20 of azimuth); a stable 2-pass LSD radix sort (16 bits per pass) orders them --
+ * O(n), ~20 ms for 4M rays, and ties keep index order, so the result is deterministic. */
 int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order)
 {
     if (!s || !dirs || !order) return hrt_fail(HRT_E_INVALID, "hrt_launch_order_host: NULL argument");
     const uint64_t n = hrt_shard_num_local(s);
     if (n == 0 || n > 0xffffffffull) return hrt_fail(HRT_E_INVALID, "hrt_launch_order_host: bad shard");
-    uint64_t *key = (uint64_t *)malloc(n * sizeof(uint64_t));
-    if (!key) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    uint32_t *key = (uint32_t *)malloc(n * sizeof(uint32_t));
+    uint32_t *tmp = (uint32_t *)malloc(n * sizeof(uint32_t));
+    uint32_t *cnt = (uint32_t *)calloc(65537, sizeof(uint32_t));
+    if (!key || !tmp || !cnt) {
+        free(key); free(tmp); free(cnt);
+        return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    }
     uint32_t nbands = (uint32_t)sqrt((double)n / 128.0);
     if (nbands < 1) nbands = 1;
     if (nbands > 4095) nbands = 4095;
@@ -345,16 +346,29 @@ int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order
         double z = d[2] > 1.f ? 1.0 : (d[2] < -1.f ? -1.0 : (double)d[2]);
         uint32_t band = (uint32_t)(0.5 * (1.0 - z) * nbands);
         if (band >= nbands) band = nbands - 1;
-        double az = (atan2((double)d[1], (double)d[0]) + 3.14159265358979323846) / 6.283185307179586477;
-        if (az < 0.0) az = 0.0;
+        /* "diamond angle": monotone in the true azimuth, no atan2 -- only the ORDER matters */
+        const double ax = fabs((double)d[0]), ay = fabs((double)d[1]);
+        double t = (ax + ay > 0.0) ? ay / (ax + ay) : 0.0;            /* 0..1 within a quadrant */
+        double az = d[0] >= 0.f ? (d[1] >= 0.f ? t : 4.0 - t) : (d[1] >= 0.f ? 2.0 - t : 2.0 + t);
+        az *= 0.25;
+        if (!(az >= 0.0)) az = 0.0;
         if (az > 0.999999) az = 0.999999;
         if (band & 1u) az = 0.999999 - az;   /* serpentine */
-        const uint32_t q = (uint32_t)(az * 1048576.0);
-        key[i] = ((uint64_t)band << 52) | ((uint64_t)q << 32) | (uint64_t)i;
+        key[i] = (band << 20) | (uint32_t)(az * 1048576.0);
     }
-    qsort(key, n, sizeof(uint64_t), cmp_u64);
-    for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)(key[i] & 0xffffffffull);
-    free(key);
+    /* pass 1: by the low 16 key bits, index order -> tmp holds indices */
+    for (uint64_t i = 0; i < n; ++i) cnt[(key[i] & 0xffffu) + 1]++;
+    for (uint32_t k = 0; k < 65536; ++k) cnt[k + 1] += cnt[k];
+    for (uint64_t i = 0; i < n; ++i) tmp[cnt[key[i] & 0xffffu]++] = (uint32_t)i;
+    /* pass 2: by the high 16 bits, stable over pass 1's order */
+    memset(cnt, 0, 65537 * sizeof(uint32_t));
+    for (uint64_t i = 0; i < n; ++i) cnt[(key[i] >> 16) + 1]++;
+    for (uint32_t k = 0; k < 65536; ++k) cnt[k + 1] += cnt[k];
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t idx = tmp[i];
+        order[cnt[key[idx] >> 16]++] = idx;
+    }
+    free(key); free(tmp); free(cnt);
     return HRT_OK;
 }
 

@@ -26,17 +26,32 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in rows:
             w.writerow({k: r[k] for k in keep})
     cal = [float(r["Counter_Value"]) for r in rows if "selftest" in r["Kernel_Name"]][0]
-    b = [float(r["Counter_Value"]) for r in rows if "bounce" in r["Kernel_Name"]]
-    n_launch = len([r for r in rows if "los" in r["Kernel_Name"]])
-    per_step = len(b) // n_launch
-    raw[ctr] = dict(corr=TRUE_KIB / cal, per_launch=[sum(b[i::per_step]) / n_launch for i in range(per_step)])
+    n_steps = len([r for r in rows if "los" in r["Kernel_Name"]])
+    # one "launch" of the bounce = trace kernel + shade kernel (+ the scan/move kernels of the
+    # stable compaction that follow it): sum their counters per trace-kernel dispatch
+    per, kinds = [], {}
+    for r in rows:
+        n = r["Kernel_Name"]
+        if "selftest" in n or "los" in n:
+            continue
+        if "trace" in n:
+            per.append(0.0)
+        per[-1] += float(r["Counter_Value"])
+        k = "trace" if "trace" in n else "shade" if "shade" in n else "compaction"
+        kinds[k] = kinds.get(k, 0.0) + float(r["Counter_Value"]) / n_steps
+    per_step = len(per) // n_steps
+    raw[ctr] = dict(corr=TRUE_KIB / cal, per_launch=[sum(per[i::per_step]) / n_steps for i in range(per_step)],
+                    by_kernel_KiB_per_step=kinds)
 
 fetch = [x * raw["FETCH_SIZE"]["corr"] * 1024 for x in raw["FETCH_SIZE"]["per_launch"]]
 write = [x * raw["WRITE_SIZE"]["corr"] * 1024 for x in raw["WRITE_SIZE"]["per_launch"]]
 path = os.path.join(HERE, "pmc_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[workload] = dict(
-    n_gpus=1, kernel="hrt_bounce_kernel", round=tag,
+    n_gpus=1, kernel="hrt_trace_kernel + hrt_shade_kernel (+ scan/move of the compaction)", round=tag,
+    by_kernel_bytes_per_step={k: dict(fetch=raw["FETCH_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["FETCH_SIZE"]["corr"] * 1024,
+                                      write=raw["WRITE_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["WRITE_SIZE"]["corr"] * 1024)
+                              for k in ("trace", "shade", "compaction")},
     source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/%s_pmc_*_%s.csv); "
            "KiB counters, calibrated on a known-traffic launch of the same access pattern: "
            "FETCH_SIZE x%.3f (gfx950 half-count), WRITE_SIZE x%.3f" % (tag, workload, raw["FETCH_SIZE"]["corr"], raw["WRITE_SIZE"]["corr"]),
