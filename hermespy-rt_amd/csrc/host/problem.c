@@ -393,7 +393,6 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     L->off_hits = off;   L->hit_block_bytes = (uint64_t)HRT_HIT_FIELDS * cap * 4; off += nb * L->hit_block_bytes;
     L->off_recs = off;   L->rec_block_bytes = (uint64_t)p->num_rx * HRT_REC_FIELDS * cap * 4; off += nb * L->rec_block_bytes;
     L->off_masks = off;  off += round_up(nb * p->num_rx * (cap / 64) * 8, 256);
-    L->off_stage = off;  off += L->hit_block_bytes;
     L->off_chunk_cnt = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
     L->off_chunk_off = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
     L->off_res = off;    off += ((uint64_t)p->num_rx + 1) * 2 * cap * 4;
@@ -432,13 +431,13 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
     K.off_counts = L.off_counts; K.off_los = L.off_los; K.off_hits = L.off_hits;
     K.hit_block_bytes = L.hit_block_bytes; K.off_recs = L.off_recs;
     K.rec_block_bytes = L.rec_block_bytes; K.off_masks = L.off_masks;
-    K.off_stage = L.off_stage; K.off_chunk_cnt = L.off_chunk_cnt; K.off_chunk_off = L.off_chunk_off;
+    K.off_chunk_cnt = L.off_chunk_cnt; K.off_chunk_off = L.off_chunk_off;
     K.off_res = L.off_res;
 
     HRT_HIP(hrt_hip_set_device(p->device), "hipSetDevice");
     const uint32_t nb = s->num_bounces;
-    /* events: [0,1] around LoS; per launch b: start, end of trace (= start of shade), end of
-     * shade (= start of compaction), end of compaction */
+    /* events: [0,1] around LoS; per launch b: start, end of trace (= start of scan), end of
+     * scan (= start of shade), end of shade */
     void *ev[2 + 4 * 34] = {0};
     const uint32_t n_ev = times ? 2 + 4 * (nb + 1) : 0;
     for (uint32_t i = 0; i < n_ev; ++i) {
@@ -458,9 +457,9 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
         if (times) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
         STEP(hrt_hip_launch_trace(&K, b, stream));
         if (times) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
-        STEP(hrt_hip_launch_shade(&K, b, stream));
+        if (b < nb) STEP(hrt_hip_launch_scan(&K, b, stream));
         if (times) STEP(hrt_hip_event_record(ev[4 + 4 * b], stream));
-        if (b < nb) STEP(hrt_hip_launch_compact(&K, b, stream));
+        STEP(hrt_hip_launch_shade(&K, b, stream));
         if (times) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
     }
     if (times && !hip) {
@@ -469,8 +468,8 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
         if (!hip) STEP(hrt_hip_event_elapsed_ms(ev[0], ev[1], &times->los_ms));
         for (uint32_t b = 0; b <= nb && !hip; ++b) {
             STEP(hrt_hip_event_elapsed_ms(ev[2 + 4 * b], ev[3 + 4 * b], &times->trace_ms[b]));
-            STEP(hrt_hip_event_elapsed_ms(ev[3 + 4 * b], ev[4 + 4 * b], &times->shade_ms[b]));
-            STEP(hrt_hip_event_elapsed_ms(ev[4 + 4 * b], ev[5 + 4 * b], &times->compact_ms[b]));
+            STEP(hrt_hip_event_elapsed_ms(ev[3 + 4 * b], ev[4 + 4 * b], &times->compact_ms[b]));
+            STEP(hrt_hip_event_elapsed_ms(ev[4 + 4 * b], ev[5 + 4 * b], &times->shade_ms[b]));
         }
         times->num_bounce_launches = nb + 1;
     }

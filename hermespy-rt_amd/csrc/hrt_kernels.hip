@@ -604,10 +604,6 @@ enum : uint32_t {
 };
 enum : uint32_t { R_A0 = 0, R_A1, R_A2, R_A3, R_TAU, R_DX, R_DY, R_DZ, R_DFS };
 
-__device__ __forceinline__ float *stage_field(const hrt_kparams &P, uint32_t f)
-{
-    return reinterpret_cast<float *>(P.ws + P.off_stage + (uint64_t)f * P.cap * 4u);
-}
 // result of trace k of live-list entry i: closest triangle (or HRT_NO_HIT) and its distance
 __device__ __forceinline__ uint32_t *res_tri(const hrt_kparams &P, uint32_t k)
 {
@@ -646,7 +642,7 @@ __device__ __forceinline__ F3 shadow_dir(F3 o, F3 rx, float &d2rx)
 // workgroup walks units, a wave does ONE trace per unit for 64 rays: it needs only the ray
 // origin/direction, so the register footprint is small and the occupancy high.  Results
 // (closest triangle, distance) go to res_tri/res_t[k][i]; all shading is the SHADE kernel's.
-// LDS image: [num_tri*5 float4 rows (if staged)][num_rx RX pos][4 waves x 16 u64 masks]
+// LDS image: [num_tri*5 float4 rows (if staged)][num_rx RX pos][4 waves x 16 u64 masks][4 u32]
 // ===================================================================================
 #ifndef HRT_TRACE_WAVES_PER_SIMD
 #define HRT_TRACE_WAVES_PER_SIMD 1
@@ -674,6 +670,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     float4 *l_rx = lds + (TRI_IN_LDS ? HRT_ROW * T : 0u);
     unsigned long long *l_mask = reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
                                  (tid >> 6) * kMaskRounds;
+    uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(
+        reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) + (HRT_BLOCK / 64u) * kMaskRounds);
     if (TRI_IN_LDS)
         for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
     for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
@@ -721,6 +719,18 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
         if (valid) {
             res_tri(P, k)[i] = h.tri;
             res_t(P, k)[i] = h.t;
+        }
+        // the bounce itself: how many rays of this chunk survive.  The scan of these counts runs
+        // BEFORE the shade kernel, which can then write every survivor straight to its final
+        // place in the next live list (stable compaction without a staging copy).
+        if (!shadow) {
+            const unsigned long long hm = __ballot(valid && h.tri != HRT_NO_HIT);
+            if (lane == 0) l_wcnt[tid >> 6] = (uint32_t)__popcll(hm);
+            __syncthreads();
+            if (tid == 0)
+                reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] =
+                    l_wcnt[0] + l_wcnt[1] + l_wcnt[2] + l_wcnt[3];
+            __syncthreads();
         }
     }
 }
@@ -890,47 +900,44 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_shade_kernel(const hrt_kparams 
                     o = add3(o, mul3(d, 1e-4f));
                 }
             }
-            // STABLE compaction, step 1: survivors of this 256-ray chunk, in input order, go to
-            // the front of the chunk's slice of the staging block; the chunk's count goes to
-            // chunk_cnt.  hrt_scan_kernel / hrt_move_kernel then concatenate the slices in
-            // chunk order, so the next live list keeps the (coherent) order of this one.
+            // STABLE compaction: survivors of this 256-entry chunk, in input order, go to
+            // chunk_off[chunk] + rank of the next live list.  chunk_off is the exclusive scan
+            // (hrt_scan_kernel, run between the trace and the shade kernel) of the per-chunk
+            // survivor counts the trace kernel produced -- so the next list keeps the (coherent)
+            // order of this one, without a staging copy.
             const unsigned long long m = __ballot(hit);
             if (lane == 0) l_wcnt[wave] = (uint32_t)__popcll(m);
             __syncthreads();
-            uint32_t before = 0, total = 0;
+            uint32_t before = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) {
-                const uint32_t c = l_wcnt[w];
-                before += (w < wave) ? c : 0u;
-                total += c;
-            }
+            for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) before += (w < wave) ? l_wcnt[w] : 0u;
             __syncthreads();
             const uint32_t chunk = (uint32_t)(base / HRT_BLOCK);
-            if (tid == 0) reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] = total;
             if (hit) {
-                const uint64_t k = base + before + lane_prefix(m);
-                stage_field(P, H_RAY)[k] = __uint_as_float(ray);
-                stage_field(P, H_TRI)[k] = __uint_as_float(ntri);
-                stage_field(P, H_THETA)[k] = nth;
-                stage_field(P, H_FS0)[k] = fs0;
-                stage_field(P, H_OX)[k] = o.x;
-                stage_field(P, H_OY)[k] = o.y;
-                stage_field(P, H_OZ)[k] = o.z;
-                stage_field(P, H_DX)[k] = d.x;
-                stage_field(P, H_DY)[k] = d.y;
-                stage_field(P, H_DZ)[k] = d.z;
-                stage_field(P, H_A0)[k] = a0;
-                stage_field(P, H_A1)[k] = a1;
-                stage_field(P, H_A2)[k] = a2;
-                stage_field(P, H_A3)[k] = a3;
-                stage_field(P, H_TAU)[k] = tau;
+                const uint64_t k = (uint64_t)reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_off)[chunk] +
+                                   before + lane_prefix(m);
+                hit_field(P, b, H_RAY)[k] = __uint_as_float(ray);
+                hit_field(P, b, H_TRI)[k] = __uint_as_float(ntri);
+                hit_field(P, b, H_THETA)[k] = nth;
+                hit_field(P, b, H_FS0)[k] = fs0;
+                hit_field(P, b, H_OX)[k] = o.x;
+                hit_field(P, b, H_OY)[k] = o.y;
+                hit_field(P, b, H_OZ)[k] = o.z;
+                hit_field(P, b, H_DX)[k] = d.x;
+                hit_field(P, b, H_DY)[k] = d.y;
+                hit_field(P, b, H_DZ)[k] = d.z;
+                hit_field(P, b, H_A0)[k] = a0;
+                hit_field(P, b, H_A1)[k] = a1;
+                hit_field(P, b, H_A2)[k] = a2;
+                hit_field(P, b, H_A3)[k] = a3;
+                hit_field(P, b, H_TAU)[k] = tau;
             }
         }
     }
 }
 
-// STABLE compaction, step 2: exclusive scan of the per-chunk survivor counts of bounce b (one
-// workgroup; at most cap/256 chunks) -> chunk_off[], and the total -> counts[b+1].
+// STABLE compaction: exclusive scan of the per-chunk survivor counts of bounce b (written by the
+// trace kernel; one workgroup; at most cap/256 chunks) -> chunk_off[], total -> counts[b+1].
 __global__ __launch_bounds__(1024) void hrt_scan_kernel(const hrt_kparams P, const uint32_t b)
 {
     __shared__ uint32_t part[1024];
@@ -959,64 +966,77 @@ __global__ __launch_bounds__(1024) void hrt_scan_kernel(const hrt_kparams P, con
     if (threadIdx.x == 1023u) counts[b + 1] = part[1023];
 }
 
-// STABLE compaction, step 3: slice c of the staging block -> hit block b at chunk_off[c].
-__global__ __launch_bounds__(HRT_BLOCK) void hrt_move_kernel(const hrt_kparams P,
-                                                             const uint32_t b)
-{
-    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_cnt);
-    const uint32_t *off = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_off);
-    const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
-    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
-    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const uint32_t n = cnt[c], dst = off[c];
-        if (threadIdx.x < n) {
-            const uint64_t src = (uint64_t)c * HRT_BLOCK + threadIdx.x;
-#pragma unroll
-            for (uint32_t f = 0; f < 15u; ++f)
-                hit_field(P, b, f)[dst + threadIdx.x] = stage_field(P, f)[src];
-        }
-    }
-}
-
-// LoS pass, one lane per (rx, tx) pair (src/compute_paths.c:515-577).  Tiny: one workgroup.
+// LoS pass (src/compute_paths.c:515-577): one WAVE per (rx, tx) pair, the lanes share the
+// triangle loop (lane l tests triangles l, l+64, ... with the reference's plain sequence), then
+// a lexicographic (distance, index) minimum over the wave -- the same winner as the reference's
+// sequential scan with its strict '<' (lowest index on equal distance).
 // Output per pair: HRT_LOS_FLOATS floats {status, a, tau, dir_tx xyz, freq_shift, -}.
 __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
 {
     const float4 *tri = reinterpret_cast<const float4 *>(P.tri);
     float *out = reinterpret_cast<float *>(P.ws + P.off_los);
     const uint32_t n = P.num_rx * P.num_tx;
-    for (uint32_t off = threadIdx.x; off < n; off += HRT_BLOCK) {
-        const uint32_t rx = off / P.num_tx, tx = off - rx * P.num_tx;
-        const F3 o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
-        const F3 r = {P.rx_pos[3 * rx], P.rx_pos[3 * rx + 1], P.rx_pos[3 * rx + 2]};
-        const F3 d = sub3(r, o);
-        float *q = out + 8u * off;
-        uint32_t status;
-        float a = 0.f, tau = 0.f, fs = 0.f;
-        F3 u = {0.f, 0.f, 0.f};
-        if (dot3(d, d) < kEps) {
-            status = 0u;   // coincident: unit gain, zero delay (:531-544)
-            a = 1.f;
-        } else {
-            // per-lane triangle loop over the global table (different rays per lane, same
-            // triangle index: still wave-uniform addresses)
-            const Hit h = closest_hit_plain(tri, P.num_tri, o, d);
-            if (h.tri != HRT_NO_HIT && h.t <= 1.f) {
-                status = 1u;   // blocked (:548-554)
-            } else {
-                status = 2u;
-                const float dist = sqrtf(dot3(d, d));
-                u = {d.x / dist, d.y / dist, d.z / dist};
-                const float fsl = P.fsl_mult * dist;   // linear, not squared (quirk Q4)
-                a = (fsl > 1.f) ? 1.f / fsl : 1.f;
-                tau = dist / kC;
-                // quirk Q5: always the FIRST tx / rx velocity
-                const F3 tv = {P.tx_vel[0], P.tx_vel[1], P.tx_vel[2]};
-                const F3 rv = {P.rx_vel[0], P.rx_vel[1], P.rx_vel[2]};
-                fs = (dot3(tv, u) - dot3(rv, u)) * P.dop_mult;
-            }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t off = blockIdx.x * (HRT_BLOCK / 64u) + (threadIdx.x >> 6);
+    if (off >= n) return;   // whole wave
+    const uint32_t rx = off / P.num_tx, tx = off - rx * P.num_tx;
+    const F3 o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
+    const F3 r = {P.rx_pos[3 * rx], P.rx_pos[3 * rx + 1], P.rx_pos[3 * rx + 2]};
+    const F3 d = sub3(r, o);
+    float *q = out + 8u * off;
+    uint32_t status;
+    float a = 0.f, tau = 0.f, fs = 0.f;
+    F3 u = {0.f, 0.f, 0.f};
+    if (dot3(d, d) < kEps) {   // wave-uniform: every lane holds the same pair
+        status = 0u;           // coincident: unit gain, zero delay (:531-544)
+        a = 1.f;
+    } else {
+        float best = 1e9f;
+        uint32_t who = HRT_NO_HIT;
+        for (uint32_t j = lane; j < P.num_tri; j += 64u) {
+            const float4 q0 = tri[HRT_ROW * j], q1 = tri[HRT_ROW * j + 1], q2 = tri[HRT_ROW * j + 2];
+            const F3 v1 = {q0.x, q0.y, q0.z};
+            const F3 e1 = {q0.w, q1.x, q1.y};
+            const F3 e2 = {q1.z, q1.w, q2.x};
+            const F3 pv = cross3(d, e2);
+            const float det = dot3(e1, pv);
+            if (det > -kEps && det < kEps) continue;
+            const F3 s = sub3(o, v1);
+            const float uu = dot3(s, pv) / det;
+            if (uu < -kEps || uu > kOnePlusEps) continue;
+            const F3 qq = cross3(s, e1);
+            const float vv = dot3(d, qq) / det;
+            const float ww = uu + vv;
+            if (vv < -kEps || ww > kOnePlusEps) continue;
+            const float dist = dot3(e2, qq) / det;
+            if (dist > kEps && dist < best) { best = dist; who = j; }   // ascending j per lane
         }
+        // accepted distances are positive floats: their bit patterns order like the values
+        uint32_t kd = __float_as_uint(best), kj = who;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t od = (uint32_t)__shfl_xor((int)kd, m), oj = (uint32_t)__shfl_xor((int)kj, m);
+            const bool take = (od < kd) || (od == kd && oj < kj);
+            kd = take ? od : kd;
+            kj = take ? oj : kj;
+        }
+        const float t = __uint_as_float(kd);
+        if (kj != HRT_NO_HIT && t <= 1.f) {
+            status = 1u;   // blocked (:548-554)
+        } else {
+            status = 2u;
+            const float dist = sqrtf(dot3(d, d));
+            u = {d.x / dist, d.y / dist, d.z / dist};
+            const float fsl = P.fsl_mult * dist;   // linear, not squared (quirk Q4)
+            a = (fsl > 1.f) ? 1.f / fsl : 1.f;
+            tau = dist / kC;
+            // quirk Q5: always the FIRST tx / rx velocity
+            const F3 tv = {P.tx_vel[0], P.tx_vel[1], P.tx_vel[2]};
+            const F3 rv = {P.rx_vel[0], P.rx_vel[1], P.rx_vel[2]};
+            fs = (dot3(tv, u) - dot3(rv, u)) * P.dop_mult;
+        }
+    }
+    if (lane == 0) {
         q[0] = __uint_as_float(status);
         q[1] = a; q[2] = tau; q[3] = u.x; q[4] = u.y; q[5] = u.z; q[6] = fs; q[7] = 0.f;
     }
@@ -1094,7 +1114,9 @@ int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b)
 
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream)
 {
-    hipLaunchKernelGGL(hrt_los_kernel, dim3(1), dim3(HRT_BLOCK), 0, (hipStream_t)stream, *P);
+    const uint32_t pairs = P->num_rx * P->num_tx, per_block = HRT_BLOCK / 64u;
+    hipLaunchKernelGGL(hrt_los_kernel, dim3((pairs + per_block - 1) / per_block), dim3(HRT_BLOCK), 0,
+                       (hipStream_t)stream, *P);
     return (int)hipGetLastError();
 }
 
@@ -1121,7 +1143,7 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
     const bool in_lds = tri_bytes <= HRT_LDS_TRI_BYTES_MAX;
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * 8u;
+                       (HRT_BLOCK / 64u) * kMaskRounds * 8u + 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
@@ -1152,16 +1174,11 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
     return (int)hipGetLastError();
 }
 
-// stable compaction of the survivors of `bounce` (scan of chunk counts, then the move)
-int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream)
+// stable compaction of the survivors of `bounce`: scan of the chunk counts (between the trace
+// and the shade kernel)
+int hrt_hip_launch_scan(const hrt_kparams *P, uint32_t bounce, void *stream)
 {
-    const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
-    uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
-    if (blocks > HRT_SHADE_GRID) blocks = HRT_SHADE_GRID;
-    if (blocks == 0) blocks = 1;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(hrt_scan_kernel, dim3(1), dim3(1024), 0, st, *P, bounce);
-    hipLaunchKernelGGL(hrt_move_kernel, dim3((uint32_t)blocks), dim3(HRT_BLOCK), 0, st, *P, bounce);
+    hipLaunchKernelGGL(hrt_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *P, bounce);
     return (int)hipGetLastError();
 }
 

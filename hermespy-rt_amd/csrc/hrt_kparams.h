@@ -44,7 +44,7 @@ typedef struct {
     uint8_t *ws;
     uint64_t cap;
     uint64_t off_counts, off_los, off_hits, hit_block_bytes, off_recs, rec_block_bytes,
-        off_masks, off_stage, off_chunk_cnt, off_chunk_off, off_res;
+        off_masks, off_chunk_cnt, off_chunk_off, off_res;
 } hrt_kparams;
 
 /* ---- the shim (hrt_kernels.hip).  All return 0 or a positive hipError_t. ---- */
@@ -60,7 +60,7 @@ int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
-int hrt_hip_launch_compact(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_launch_scan(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
 int hrt_hip_read_stats(unsigned long long *out24, int reset);
 /* events: opaque handles */

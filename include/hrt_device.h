@@ -126,8 +126,8 @@ typedef struct {
                                                        + (rx*HRT_REC_FIELDS + f)*cap*4 */
     uint64_t rec_block_bytes;
     uint64_t off_masks;         /* u64 words of (b, rx) at off_masks + (b*num_rx + rx)*(cap/64)*8 */
-    /* scratch of the stable compaction (one hit block of staging, per-chunk counts/offsets) */
-    uint64_t off_stage, off_chunk_cnt, off_chunk_off;
+    /* scratch of the stable compaction (per-chunk survivor counts and their exclusive scan) */
+    uint64_t off_chunk_cnt, off_chunk_off;
     /* trace results of one launch: for trace kind k (0..num_rx-1 shadow to rx k, num_rx the
      * bounce itself) u32 triangle[cap] then f32 distance[cap] at off_res + (2k, 2k+1)*cap*4 */
     uint64_t off_res;
@@ -140,14 +140,15 @@ typedef struct {
     float los_ms;
     float trace_ms[33];         /* trace kernel (all intersection work) of launch b = 0..num_bounces */
     float shade_ms[33];         /* shade kernel (records, Fresnel, reflect) of launch b */
-    float compact_ms[33];       /* scan + move kernels after launch b (0 for the last) */
+    float compact_ms[33];       /* scan kernel of the stable compaction of launch b (0 for the last) */
     uint32_t num_bounce_launches;
 } hrt_kernel_times;
 
 /* Enqueue the whole path on `stream`: zero the counters, LoS kernel, then num_bounces + 1
  * launches; launch b = trace kernel (the num_rx shadow rays of every hit of bounce b-1 and the
- * rays of bounce b: intersection only) + shade kernel (scatter records of bounce b-1; Fresnel,
- * delay, reflection of bounce b) + the two small kernels of the stable compaction.
+ * rays of bounce b: intersection only) + a one-workgroup scan (stable compaction offsets) +
+ * shade kernel (scatter records of bounce b-1; Fresnel, delay, reflection of bounce b;
+ * survivors written in order into the next live list).
  * Asynchronous unless `times` != NULL, in which case HIP events are recorded around every
  * launch on `stream` and the call returns after the stream drained.
  * d_dirs:  device [num_local][3] floats (this shard's launch directions).
