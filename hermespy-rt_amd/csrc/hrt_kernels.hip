@@ -129,6 +129,12 @@ constexpr float kK2 = 1.f + 0x1p-20f;
 constexpr float kK3 = 1.f + 0x1p-19f;
 constexpr float kK5 = 1.1920928955078125e-07f * (1.f - 0x1p-18f);
 
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // true iff p holds in every ACTIVE lane: one v_cmp into an SGPR pair + scalar compare (hipcc's
 // __all() goes through a v_cndmask/v_cmp_ne pair)
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
@@ -463,125 +469,6 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
     return {who, best};
 }
 
-// Variant 3 ("block packet"): like variant 2, but the packet is the whole 256-ray chunk of the
-// workgroup.  The four waves publish their bounds, every thread merges them (ball of balls,
-// cone of cones), and the 256 threads cull 256 triangles per pass -- one pass for scenes up to
-// 256 triangles instead of four per wave; the four waves then walk the SAME candidate list.
-// The merged packet is wider, so it keeps more candidates, but the culling cost per wave drops
-// 4x.  Soundness is unchanged: the merged ball/cone contain every ray of every wave.
-constexpr uint32_t kBlockRounds = 4;   // 4 x 256 triangles culled; beyond: tested unculled
-
-struct WaveBounds { float v[12]; };   // bc.xyz br ax.xyz cosa sina ok - -
-
-// ALL threads of the workgroup must call this (uniform control flow, contains barriers).
-template <typename TriPtr>
-__device__ __forceinline__ Hit closest_hit_block(TriPtr tri, uint32_t num_tri, F3 o, F3 d,
-                                                 bool valid, uint32_t tid, const F3 *apex,
-                                                 float *l_wb, unsigned long long *l_bmask,
-                                                 [[maybe_unused]] int kind)
-{
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    float best = 1e9f;
-    uint32_t who = HRT_NO_HIT;
-    bool usable;
-    {
-        const Ball wb = origin_ball(o, valid);
-        const Packet wp = packet_bounds(wb, d, valid, nullptr);
-        if (lane == 0) {
-            float *w = l_wb + 12u * wave;
-            w[0] = wb.c.x; w[1] = wb.c.y; w[2] = wb.c.z; w[3] = wb.r;
-            w[4] = wp.ax.x; w[5] = wp.ax.y; w[6] = wp.ax.z; w[7] = wp.cosa;
-            w[8] = wp.sina; w[9] = wb.ok ? (wp.usable ? 1.f : 2.f) : 0.f;   // 0: no rays
-        }
-        __syncthreads();
-        // merge (identical in every thread)
-        Packet P;
-        F3 csum = {0.f, 0.f, 0.f}, asum = {0.f, 0.f, 0.f};
-        float nw = 0.f;
-        bool ok = true;
-#pragma unroll
-        for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) {
-            const float *q = l_wb + 12u * w;
-            const float st = q[9];
-            if (st != 0.f) {
-                csum = add3(csum, {q[0], q[1], q[2]});
-                asum = add3(asum, {q[4], q[5], q[6]});
-                nw += 1.f;
-                ok &= (st == 1.f);
-            }
-        }
-        ok &= nw > 0.f;
-        const float inw = 1.f / fmaxf(nw, 1.f);
-        P.bc = {csum.x * inw, csum.y * inw, csum.z * inw};
-        const float n2 = dot3(asum, asum);
-        const float ia = fast_rsq(fmaxf(n2, 1e-30f));
-        P.ax = {asum.x * ia, asum.y * ia, asum.z * ia};
-        float br = 0.f, cosa = 1.f;
-#pragma unroll
-        for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) {
-            const float *q = l_wb + 12u * w;
-            if (q[9] != 0.f) {
-                const F3 dc = sub3({q[0], q[1], q[2]}, P.bc);
-                br = fmaxf(br, fast_sqrt(dot3(dc, dc)) * 1.0001f + q[3]);
-                const float cb = fminf(1.f, dot3({q[4], q[5], q[6]}, P.ax)) * (1.f - 1e-5f) - 1e-6f;
-                const float sb = fast_sqrt(fmaxf(0.f, 1.f - cb * cb)) * 1.0001f + 1e-6f;
-                // cos(beta + alpha), only meaningful while beta + alpha < pi/2 (checked below)
-                const float cba = cb * q[7] - sb * q[8];
-                cosa = fminf(cosa, (cb > 0.f && q[7] > 0.f) ? cba : -1.f);
-            }
-        }
-        P.br = br;
-        P.cosa = cosa * (1.f - 1e-5f) - 1e-6f;
-        P.sina = fast_sqrt(fmaxf(0.f, 1.f - P.cosa * P.cosa)) * 1.0001f;
-        if (apex) {
-            P.oc = *apex;
-            const F3 v = sub3(*apex, P.bc);
-            P.ro = 8.f * (0.5f * kEps) * (fast_sqrt(dot3(v, v)) * 1.0001f + P.br) + 1e-7f;
-        } else {
-            P.oc = P.bc;
-            P.ro = P.br;
-        }
-        usable = ok && (n2 > 1e-12f) && (P.cosa > 0.5f);
-        HRT_STAT(kind, 0, 1);
-        HRT_STAT(kind, 1, usable ? 1 : 0);
-        if (usable) {
-            for (uint32_t base = 0, r = 0; base < num_tri && r < kBlockRounds; base += HRT_BLOCK, ++r) {
-                const uint32_t jl = base + tid;
-                bool cand = false;
-                if (jl < num_tri)
-                    cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
-                                         tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 4]);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
-                if (lane == 0) l_bmask[r * (HRT_BLOCK / 64u) + wave] = m;
-            }
-        }
-        __syncthreads();
-    }
-    if (!usable) {
-        HRT_STAT(kind, 2, num_tri);
-        for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
-    } else {
-        for (uint32_t base = 0, r = 0; base < num_tri && r < kBlockRounds; base += HRT_BLOCK, ++r) {
-#pragma unroll
-            for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) {
-                unsigned long long m = l_bmask[r * (HRT_BLOCK / 64u) + w];
-                const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-                const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
-                m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
-                HRT_STAT(kind, 2, __popcll(m));
-                while (m) {
-                    const uint32_t j = base + 64u * w + (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1ull;
-                    HRT_STAGED_BODY(j)
-                }
-            }
-        }
-        for (uint32_t j = kBlockRounds * HRT_BLOCK; j < num_tri; ++j) HRT_STAGED_BODY(j)
-    }
-    __syncthreads();   // l_wb / l_bmask are rewritten by the next unit
-    return {who, best};
-}
-
 #ifndef HRT_TRACE_VARIANT_DEFAULT
 #define HRT_TRACE_VARIANT_DEFAULT 2
 #endif
@@ -692,11 +579,6 @@ __device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s,
 
 __device__ __noinline__ float acos_f_ool(float x) { return hrt_acosf(x); }
 
-__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 // ---- workspace addressing (include/hrt_device.h) ----
 __device__ __forceinline__ float *hit_field(const hrt_kparams &P, uint32_t b, uint32_t f)
@@ -791,8 +673,6 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
                                  (tid >> 6) * kMaskRounds;
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(
         reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) + (HRT_BLOCK / 64u) * kMaskRounds);
-    float *l_wb = reinterpret_cast<float *>(l_wcnt + 4);                       // 4 x 12 floats
-    unsigned long long *l_bmask = reinterpret_cast<unsigned long long *>(l_wb + 48);   // 16 u64
     if (TRI_IN_LDS)
         for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
     for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
@@ -832,16 +712,11 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
             const F3 w = shadow_dir(o, apex, d2rx);
             if (valid) d = w;
         }
-        Hit h;
-        if constexpr (VARIANT == 3) {
-            h = closest_hit_block(tri, T, o, d, valid, tid, shadow ? &apex : nullptr, l_wb, l_bmask,
-                                  shadow ? 2 : (first ? 0 : 1));
-        } else {
-            Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
-            if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
-            h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball, shadow ? &apex : nullptr,
-                                     l_mask, shadow ? 2 : (first ? 0 : 1));
-        }
+        Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
+        if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
+        const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball,
+                                           shadow ? &apex : nullptr, l_mask,
+                                           shadow ? 2 : (first ? 0 : 1));
         if (valid) {
             res_tri(P, k)[i] = h.tri;
             res_t(P, k)[i] = h.t;
@@ -1269,19 +1144,17 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
     const bool in_lds = tri_bytes <= HRT_LDS_TRI_BYTES_MAX;
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * 8u + 16u + 48u * 4u + 16u * 8u;
+                       (HRT_BLOCK / 64u) * kMaskRounds * 8u + 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
     if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
-        else if (variant == 3) launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
         else launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
     } else {
         if (variant == 0) launch_trace_t<false, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<false, 1>(P, bounce, nb, lds, st, &err);
-        else if (variant == 3) launch_trace_t<false, 3>(P, bounce, nb, lds, st, &err);
         else launch_trace_t<false, 2>(P, bounce, nb, lds, st, &err);
     }
     if (err != hipSuccess) return (int)err;

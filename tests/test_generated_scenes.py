@@ -72,7 +72,7 @@ print("GENERATED_OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_product_equals_oracle_on_generated_scenes(variant):
     env = dict(os.environ, HRT_TRACE_VARIANT=str(variant))
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)

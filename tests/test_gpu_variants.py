@@ -42,7 +42,7 @@ print("VARIANT_OK")
 """
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_variant_is_bit_identical(variant):
     env = dict(os.environ, HRT_TRACE_VARIANT=str(variant))
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)
