@@ -19,7 +19,7 @@ EXPORTED = (
     "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_layout_query", "hrt_trace",
     "hrt_work_from_counts", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
     "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
-    "hrt_selftest_math", "hrt_debug_kernel_stats",
+    "hrt_selftest_math", "hrt_debug_kernel_stats", "hrt_scene_import_sionna",
 )
 
 HIT_FIELDS = ("ray", "tri", "theta", "fs0", "ox", "oy", "oz", "dx", "dy", "dz",
@@ -125,6 +125,8 @@ def load():
     L.hrt_selftest_math.restype = C.c_int
     L.hrt_debug_kernel_stats.argtypes = [C.c_int, C.POINTER(u64), C.c_int]
     L.hrt_debug_kernel_stats.restype = C.c_int
+    L.hrt_scene_import_sionna.argtypes = [C.c_char_p, C.POINTER(abi.Scene)]
+    L.hrt_scene_import_sionna.restype = C.c_int
     _lib = L
     return L
 

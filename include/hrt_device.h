@@ -172,6 +172,13 @@ int hrt_device_sync(int device, void *stream);
 /* total/free HBM bytes */
 int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
+/* Sionna / Mitsuba scene (scene.xml, the PLY files it names, optional scene.csv) -> Scene, the job of
+ * the reference's importer tool (src/scene_fromSionna.c:103-488) as a library call.  `out` is
+ * filled with malloc()ed meshes (release with free_scene); the file names box.xml and
+ * simple_reflector.xml select the two built-in scenes.  See csrc/host/sionna_import.c for the
+ * accepted formats.  CLI: lib/hrt_import_sionna. */
+int hrt_scene_import_sionna(const char *xml_path, Scene *out);
+
 /* Device self test: evaluates on the GPU, over n host floats, one of the float libm
  * restatements the shading code uses -- fn 0 sinf, 1 cosf, 2 expf, 3 acosf (csrc/hrt_libm.h)
  * -- or, fn 4, the incidence angle of src/compute_paths.c:281-283 for dot(n, d) = in[i]
