@@ -2,9 +2,6 @@ set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 make -C oracle liboracle.so > gpurun_out/build.log 2>&1
-HRT_TRACE_VARIANT=4 timeout -k 10 600 python -m pytest tests/test_gpu_dense_parity.py tests/test_gpu_full_size.py -m gpu -q -x 2>&1 | grep -vE "^$" | tail -4
-for v in 2 4; do
-HRT_TRACE_VARIANT=$v timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err || (tail -30 gpurun_out/b.err; exit 1)
-python -c "
-import json; d=json.load(open('gpurun_out/b.json')); r=d['roofline']; print('variant $v', round(d['ms_per_step'],3), 'trace', [round(x,3) for x in r['trace_kernel_ms']], 'shade', [round(x,3) for x in r['shade_kernel_ms']])"
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_dense_parity.py tests/test_gpu_golden.py tests/test_gpu_pybind.py -m gpu -q -x 2>&1 | grep -vE "^$" | tail -4
+python bench.py --dropin | tee gpurun_out/dropin_c3.json
+python bench.py --dropin | python -c "import json,sys; d=json.load(sys.stdin); print({k:round(v,4) for k,v in d.items() if k.startswith('t_')})"

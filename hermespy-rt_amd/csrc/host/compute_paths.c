@@ -26,6 +26,40 @@
 
 #include "hrt_internal.h"
 
+#include <pthread.h>
+#include <unistd.h>
+
+/* ---- a minimal parallel-for over [0, n): the dense scatter is host-memory bound and every
+ * record owns its slots, so it splits into independent ranges ---- */
+typedef void (*range_fn)(void *ctx, uint64_t i0, uint64_t i1, int tid);
+typedef struct { range_fn fn; void *ctx; uint64_t i0, i1; int tid; } range_job;
+static void *range_thread(void *a)
+{
+    range_job *j = (range_job *)a;
+    j->fn(j->ctx, j->i0, j->i1, j->tid);
+    return NULL;
+}
+#define HRT_MAX_SCATTER_THREADS 32
+static void parallel_ranges(range_fn fn, void *ctx, uint64_t n, int threads)
+{
+    if (threads > HRT_MAX_SCATTER_THREADS) threads = HRT_MAX_SCATTER_THREADS;
+    if ((uint64_t)threads > n / 65536 + 1) threads = (int)(n / 65536 + 1);
+    if (threads <= 1) { fn(ctx, 0, n, 0); return; }
+    pthread_t th[HRT_MAX_SCATTER_THREADS];
+    range_job jb[HRT_MAX_SCATTER_THREADS];
+    int started = 0;
+    for (int t = 0; t < threads; ++t) {
+        jb[t] = (range_job){fn, ctx, n * (uint64_t)t / (uint64_t)threads, n * (uint64_t)(t + 1) / (uint64_t)threads, t};
+        if (t + 1 == threads || pthread_create(&th[t], NULL, range_thread, &jb[t]) != 0) {
+            jb[t].i1 = n;   /* last slice, or a thread that would not start: finish here */
+            range_thread(&jb[t]);
+            break;
+        }
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+}
+
 static int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -60,10 +94,49 @@ static void work_free(work_t *w)
     if (w->d_order) hrt_device_free(w->device, w->d_order);
     free(w->h_order);
     if (w->d_ws) hrt_device_free(w->device, w->d_ws);
-    free(w->h_dirs); free(w->h_counts); free(w->h_los); free(w->ray); free(w->tri);
-    for (int k = 0; k < 6; ++k) free(w->st[k]);
-    for (int k = 0; k < HRT_REC_FIELDS; ++k) free(w->rec[k]);
-    free(w->dirs_batch); free(w->mask); free(w->cur_rays); free(w->active); free(w->next_active);
+    free(w->h_dirs); free(w->h_counts); free(w->h_los);
+    /* D2H staging is page-locked (hipHostMalloc): 2-4x the pageable copy rate */
+    hrt_hip_host_free(w->ray); hrt_hip_host_free(w->tri);
+    for (int k = 0; k < 6; ++k) hrt_hip_host_free(w->st[k]);
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec[k]);
+    hrt_hip_host_free(w->mask);
+    free(w->dirs_batch); free(w->cur_rays); free(w->active); free(w->next_active);
+}
+
+typedef struct {
+    const hrt_shard *s;
+    const uint32_t *ray;
+    float *const *rec;
+    const uint64_t *mask;
+    ChannelInfo *scat;
+    uint64_t n_loc;
+    size_t rx, b, ntx, nb, np;
+    uint64_t unblocked[HRT_MAX_SCATTER_THREADS];
+} scatter_ctx;
+
+/* records of (bounce b, rx) -> dense slots ((rx*ntx+tx)*nb+b)*np+p   (src/compute_paths.c:674) */
+static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    scatter_ctx *c = (scatter_ctx *)vctx;
+    ChannelInfo *scat = c->scat;
+    uint64_t unb = 0;
+    for (uint64_t i = i0; i < i1; ++i) {
+        const uint32_t ql = c->ray[i];
+        const size_t tx = ql / c->n_loc;
+        const uint64_t p = hrt_shard_global_path(c->s, ql - tx * c->n_loc);
+        const size_t off = ((c->rx * c->ntx + tx) * c->nb + c->b) * c->np + p;
+        scat->a_te_re[off] = c->rec[HRT_REC_A_TE_RE][i];
+        scat->a_te_im[off] = c->rec[HRT_REC_A_TE_IM][i];
+        scat->a_tm_re[off] = c->rec[HRT_REC_A_TM_RE][i];
+        scat->a_tm_im[off] = c->rec[HRT_REC_A_TM_IM][i];
+        scat->tau[off] = c->rec[HRT_REC_TAU][i];
+        if ((c->mask[i >> 6] >> (i & 63)) & 1u) {
+            scat->directions_rx[off] = (Vec3){c->rec[HRT_REC_DIRX][i], c->rec[HRT_REC_DIRY][i], c->rec[HRT_REC_DIRZ][i]};
+            scat->freq_shift[off] -= c->rec[HRT_REC_DFS][i];       /* :722 */
+            ++unb;
+        }
+    }
+    c->unblocked[tid] += unb;
 }
 
 #define DL(dst, off, bytes)                                                              \
@@ -94,6 +167,11 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     if (rc) return rc;
     const uint32_t T = prob->num_tri;
     const size_t nq = ntx * np;
+    int scatter_threads = env_int("HRT_HOST_THREADS", 0);
+    if (scatter_threads <= 0) {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        scatter_threads = nc > 16 ? 16 : (nc > 0 ? (int)nc : 1);
+    }
 
     /* normals: the reference leaves them in the scene for the caller (:208-224) */
     {
@@ -188,12 +266,12 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         if (!w.h_order) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
         w.h_counts = (uint32_t *)calloc(nb + 2, 4);
         w.h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
-        w.ray = (uint32_t *)malloc(cap * 4);
-        w.tri = (uint32_t *)malloc(cap * 4);
-        w.mask = (uint64_t *)malloc(cap / 64 * 8);
-        int ok = w.h_counts && w.h_los && w.ray && w.tri && w.mask;
-        for (int k = 0; k < 6 && scat_rays; ++k) ok &= (w.st[k] = (float *)malloc(cap * 4)) != NULL;
-        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= (w.rec[k] = (float *)malloc(cap * 4)) != NULL;
+        int ok = w.h_counts && w.h_los;
+        ok &= hrt_hip_host_malloc((void **)&w.ray, cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&w.tri, cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&w.mask, cap / 64 * 8 + 8) == 0;
+        for (int k = 0; k < 6 && scat_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w.st[k], cap * 4) == 0;
+        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w.rec[k], cap * 4) == 0;
         if (!ok) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
     }
 
@@ -302,22 +380,13 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                 const uint64_t rb = L.off_recs + b * L.rec_block_bytes + (uint64_t)rx * HRT_REC_FIELDS * L.cap * 4;
                 for (int k = 0; k < HRT_REC_FIELDS; ++k) DL(w.rec[k], rb + (uint64_t)k * L.cap * 4, H * 4);
                 DL(w.mask, L.off_masks + ((uint64_t)b * nrx + rx) * (L.cap / 64) * 8, (H + 63) / 64 * 8);
-                for (uint64_t i = 0; i < H; ++i) {
-                    const uint32_t ql = w.ray[i];
-                    const uint64_t n_loc32 = n_loc;
-                    const size_t tx = ql / n_loc32;
-                    const uint64_t p = hrt_shard_global_path(&s, ql - tx * n_loc32);
-                    const size_t off = ((rx * ntx + tx) * nb + b) * np + p;   /* :674 */
-                    scat->a_te_re[off] = w.rec[HRT_REC_A_TE_RE][i];
-                    scat->a_te_im[off] = w.rec[HRT_REC_A_TE_IM][i];
-                    scat->a_tm_re[off] = w.rec[HRT_REC_A_TM_RE][i];
-                    scat->a_tm_im[off] = w.rec[HRT_REC_A_TM_IM][i];
-                    scat->tau[off] = w.rec[HRT_REC_TAU][i];
-                    if ((w.mask[i >> 6] >> (i & 63)) & 1u) {
-                        scat->directions_rx[off] = (Vec3){w.rec[HRT_REC_DIRX][i], w.rec[HRT_REC_DIRY][i], w.rec[HRT_REC_DIRZ][i]};
-                        scat->freq_shift[off] -= w.rec[HRT_REC_DFS][i];       /* :722 */
-                        ++st.records_unblocked;
-                    }
+                {
+                    scatter_ctx sc;
+                    memset(&sc, 0, sizeof sc);
+                    sc.s = &s; sc.ray = w.ray; sc.rec = w.rec; sc.mask = w.mask; sc.scat = scat;
+                    sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
+                    parallel_ranges(scatter_range, &sc, H, scatter_threads);
+                    for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st.records_unblocked += sc.unblocked[t];
                 }
             }
 

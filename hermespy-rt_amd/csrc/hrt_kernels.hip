@@ -1091,6 +1091,8 @@ int hrt_hip_device_count(int *n) { return (int)hipGetDeviceCount(n); }
 int hrt_hip_set_device(int dev) { return (int)hipSetDevice(dev); }
 int hrt_hip_malloc(void **p, uint64_t bytes) { return (int)hipMalloc(p, bytes ? bytes : 1); }
 int hrt_hip_free(void *p) { return (int)hipFree(p); }
+int hrt_hip_host_malloc(void **p, uint64_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault); }
+int hrt_hip_host_free(void *p) { return p ? (int)hipHostFree(p) : 0; }
 int hrt_hip_h2d(void *dst, const void *src, uint64_t bytes)
 {
     return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);

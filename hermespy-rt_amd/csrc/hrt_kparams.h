@@ -52,6 +52,8 @@ int hrt_hip_device_count(int *n);
 int hrt_hip_set_device(int dev);
 int hrt_hip_malloc(void **p, uint64_t bytes);
 int hrt_hip_free(void *p);
+int hrt_hip_host_malloc(void **p, uint64_t bytes);   /* page-locked host memory */
+int hrt_hip_host_free(void *p);
 int hrt_hip_h2d(void *dst, const void *src, uint64_t bytes);
 int hrt_hip_d2h(void *dst, const void *src, uint64_t bytes);
 int hrt_hip_memset_async(void *dst, int value, uint64_t bytes, void *stream);
