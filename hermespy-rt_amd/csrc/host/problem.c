@@ -273,21 +273,24 @@ typedef struct {
 
 /* src/compute_paths.c:444-451.  k, phi, theta are FLOAT; acos/cos/sin are the DOUBLE libm
  * functions applied to them; the products are rounded to float on store. */
+static void launch_dir_host(const hrt_shard *s, uint64_t i, float *out3)
+{
+    const float n_f = (float)s->num_paths;   /* size_t -> float in "2.f * k / num_paths" */
+    const float golden = HRT_PI_F * (1.f + sqrtf(5.f));
+    const uint64_t p = hrt_shard_global_path(s, i);
+    const float k = (float)p + .5f;
+    const float phi = (float)acos((double)(1.f - 2.f * k / n_f));
+    const float theta = golden * k;
+    const double sp = sin((double)phi);
+    out3[0] = (float)(cos((double)theta) * sp);
+    out3[1] = (float)(sin((double)theta) * sp);
+    out3[2] = (float)cos((double)phi);
+}
+
 static void *dirs_worker(void *arg)
 {
     dirs_job *jb = (dirs_job *)arg;
-    const float n_f = (float)jb->s->num_paths;   /* size_t -> float in "2.f * k / num_paths" */
-    const float golden = HRT_PI_F * (1.f + sqrtf(5.f));
-    for (uint64_t i = jb->i0; i < jb->i1; ++i) {
-        const uint64_t p = hrt_shard_global_path(jb->s, i);
-        const float k = (float)p + .5f;
-        const float phi = (float)acos((double)(1.f - 2.f * k / n_f));
-        const float theta = golden * k;
-        const double sp = sin((double)phi);
-        jb->out[3 * i] = (float)(cos((double)theta) * sp);
-        jb->out[3 * i + 1] = (float)(sin((double)theta) * sp);
-        jb->out[3 * i + 2] = (float)cos((double)phi);
-    }
+    for (uint64_t i = jb->i0; i < jb->i1; ++i) launch_dir_host(jb->s, i, jb->out + 3 * i);
     return NULL;
 }
 
@@ -322,13 +325,54 @@ int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads)
     return HRT_OK;
 }
 
+/* Launch directions generated ON THE DEVICE into d_dirs ([num_local][3] floats), bit-identical
+ * to hrt_launch_dirs_host: the device evaluates the reference's formula with its own double
+ * math library, flags every value whose rounding to float could depend on the last bits of
+ * that library, and the flagged rays (about one in a million) are recomputed here with the host
+ * libm and patched in.  Blocks until done.  *num_patched (may be NULL) reports the list length. */
+#define HRT_DIRS_FIX_CAP 65536u
+int hrt_launch_dirs_device(const hrt_shard *s, float *d_dirs, int device, void *stream,
+                           uint64_t *num_patched)
+{
+    if (!s || !d_dirs || s->count == 0 || s->rank >= s->count || s->num_paths == 0)
+        return hrt_fail(HRT_E_INVALID, "hrt_launch_dirs_device: bad argument");
+    const uint32_t ch = shard_chunk(s);
+    if (ch % 64u) return hrt_fail(HRT_E_INVALID, "shard chunk %u is not a multiple of 64", ch);
+    const uint64_t n = hrt_shard_num_local(s);
+    HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
+    void *d_fix = NULL;
+    HRT_HIP(hrt_hip_malloc(&d_fix, (uint64_t)(HRT_DIRS_FIX_CAP + 1) * 4), "hipMalloc(fix list)");
+    int rc = HRT_OK, e;
+    uint32_t *h_fix = (uint32_t *)malloc((size_t)(HRT_DIRS_FIX_CAP + 1) * 4);
+    if (!h_fix) rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
+    if (!rc && (e = hrt_hip_memset_async(d_fix, 0, 4, stream))) rc = hrt_fail_hip(e, "hipMemsetAsync");
+    if (!rc && (e = hrt_hip_launch_dirs(s->num_paths, s->rank, s->count, ch, n, d_dirs, (uint32_t *)d_fix,
+                                        (uint32_t *)d_fix + 1, HRT_DIRS_FIX_CAP, stream)))
+        rc = hrt_fail_hip(e, "hrt_launch_dirs_kernel");
+    if (!rc && (e = hrt_hip_stream_sync(stream))) rc = hrt_fail_hip(e, "hipStreamSynchronize");
+    if (!rc && (e = hrt_hip_d2h(h_fix, d_fix, 4))) rc = hrt_fail_hip(e, "hipMemcpy D2H");
+    if (!rc && h_fix[0] > HRT_DIRS_FIX_CAP)
+        rc = hrt_fail(HRT_E_CAPACITY, "launch-direction fix list overflow (%u): use the host generator", h_fix[0]);
+    if (!rc && h_fix[0] && (e = hrt_hip_d2h(h_fix + 1, (uint32_t *)d_fix + 1, (uint64_t)h_fix[0] * 4)))
+        rc = hrt_fail_hip(e, "hipMemcpy D2H");
+    for (uint32_t k = 0; !rc && k < h_fix[0]; ++k) {
+        float v[3];
+        launch_dir_host(s, h_fix[1 + k], v);
+        if ((e = hrt_hip_h2d(d_dirs + 3 * (uint64_t)h_fix[1 + k], v, 12))) rc = hrt_fail_hip(e, "hipMemcpy H2D");
+    }
+    if (!rc && num_patched) *num_patched = h_fix[0];
+    free(h_fix);
+    hrt_hip_free(d_fix);
+    return rc;
+}
+
 /* Coherent launch order: z-bands of about sqrt(n/128) rows, serpentine in azimuth, so 64
  * consecutive positions are a roughly square patch of the sphere.  Keys are 32 bits (12 bits of
  * band, 20 of azimuth); a stable 2-pass LSD radix sort (16 bits per pass) orders them --
  * O(n), ~20 ms for 4M rays, and ties keep index order, so the result is deterministic. */
 int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order)
 {
-    if (!s || !dirs || !order) return hrt_fail(HRT_E_INVALID, "hrt_launch_order_host: NULL argument");
+    if (!s || !order) return hrt_fail(HRT_E_INVALID, "hrt_launch_order_host: NULL argument");
     const uint64_t n = hrt_shard_num_local(s);
     if (n == 0 || n > 0xffffffffull) return hrt_fail(HRT_E_INVALID, "hrt_launch_order_host: bad shard");
     uint32_t *key = (uint32_t *)malloc(n * sizeof(uint32_t));
@@ -341,8 +385,23 @@ int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order
     uint32_t nbands = (uint32_t)sqrt((double)n / 128.0);
     if (nbands < 1) nbands = 1;
     if (nbands > 4095) nbands = 4095;
+    const float n_f = (float)s->num_paths, golden = HRT_PI_F * (1.f + sqrtf(5.f));
     for (uint64_t i = 0; i < n; ++i) {
-        const float *d = dirs + 3 * i;
+        float dd[3];
+        const float *d = dirs ? dirs + 3 * i : dd;
+        if (!dirs) {
+            /* no directions at hand (they were generated on the device): the key needs only
+             * the polar coordinate z = 1 - 2k/N and the azimuth theta mod 2 pi, both available
+             * without libm (fmod is exact); any monotone proxy gives the same order quality */
+            const float k = (float)hrt_shard_global_path(s, i) + .5f;
+            const double th = fmod((double)(golden * k), 6.283185307179586477);
+            const double thq = th * (4.0 / 6.283185307179586477);   /* quadrant coordinate 0..4 */
+            const int qd = (int)thq;
+            const double fr = thq - qd;   /* diamond-angle-like proxy of (cos, sin) */
+            dd[0] = (qd == 0 || qd == 3) ? (float)(qd == 0 ? 1.0 - fr : fr) : (float)(qd == 1 ? -fr : -(1.0 - fr));
+            dd[1] = (qd == 0 || qd == 1) ? (float)(qd == 0 ? fr : 1.0 - fr) : (float)(qd == 2 ? -fr : -(1.0 - fr));
+            dd[2] = 1.f - 2.f * k / n_f;
+        }
         double z = d[2] > 1.f ? 1.0 : (d[2] < -1.f ? -1.0 : (double)d[2]);
         uint32_t band = (uint32_t)(0.5 * (1.0 - z) * nbands);
         if (band >= nbands) band = nbands - 1;

@@ -1043,6 +1043,54 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
     }
 }
 
+// ===================================================================================
+// Launch directions on the device.  The reference evaluates
+//   k = p + .5f; phi = (float)acos(1.f - 2.f*k/N); theta = pi_f*(1.f + sqrtf(5.f))*k   (float)
+//   d = ((float)(cos(theta)*sin(phi)), (float)(sin(theta)*sin(phi)), (float)cos(phi))   (double libm)
+// (src/compute_paths.c:444-451).  The float steps are exact IEEE operations and identical here.
+// The double-precision acos/cos/sin are the DEVICE library's, which may differ from glibc's in
+// the last bits -- harmless unless the value is about to be rounded to float right next to a
+// rounding boundary.  So every double -> float rounding is checked: if the double lies within
+// `guard` relative (2^-44, thousands of double ulps; both libraries are good to a few) of the
+// midpoint between two floats, the ray is put on a fix list and the HOST recomputes it with
+// its own libm.  Expected list length ~ 5e-7 per ray (measured: tests/test_gpu_launch_dirs.py);
+// everything else is provably the same float.  An overfull list makes the caller fall back to
+// the host generator.
+// ===================================================================================
+__device__ __forceinline__ bool near_float_boundary(double x, float f)
+{
+    const double up = 0.5 * ((double)f + (double)nextafterf(f, 3.0e38f));
+    const double dn = 0.5 * ((double)f + (double)nextafterf(f, -3.0e38f));
+    const double dist = fmin(fabs(x - up), fabs(x - dn));
+    return !(dist > fabs(x) * 0x1p-44 + 1e-300);
+}
+
+__global__ void hrt_launch_dirs_kernel(uint64_t num_paths, uint32_t rank, uint32_t count,
+                                       uint32_t chunk, uint64_t num_local, float *dirs,
+                                       uint32_t *fix_count, uint32_t *fix_list, uint32_t fix_cap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_local) return;
+    const uint64_t p = ((i / chunk) * count + rank) * chunk + i % chunk;
+    const float k = (float)p + .5f;
+    const float arg = 1.f - 2.f * k / (float)num_paths;
+    const double ph_d = acos((double)arg);
+    const float phi = (float)ph_d;
+    const float theta = kPi * (1.f + sqrtf(5.f)) * k;
+    const double sp = sin((double)phi);
+    const double x = cos((double)theta) * sp, y = sin((double)theta) * sp, z = cos((double)phi);
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    dirs[3 * i] = fx;
+    dirs[3 * i + 1] = fy;
+    dirs[3 * i + 2] = fz;
+    // the products inherit ~2 ulp from each factor: still far inside the guard
+    if (near_float_boundary(ph_d, phi) || near_float_boundary(x, fx) ||
+        near_float_boundary(y, fy) || near_float_boundary(z, fz)) {
+        const uint32_t slot = atomicAdd(fix_count, 1u);
+        if (slot < fix_cap) fix_list[slot] = (uint32_t)i;
+    }
+}
+
 // evaluates one of the hrt_libm.h functions (or the incidence-angle acos) over an array: the
 // GPU side of tests/test_gpu_libm.py
 __global__ void hrt_selftest_math_kernel(int fn, const float *in, float *out, uint64_t n)
@@ -1182,6 +1230,17 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
 int hrt_hip_launch_scan(const hrt_kparams *P, uint32_t bounce, void *stream)
 {
     hipLaunchKernelGGL(hrt_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *P, bounce);
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
+                        uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
+                        uint32_t *d_fix_list, uint32_t fix_cap, void *stream)
+{
+    if (num_local == 0) return 0;
+    hipLaunchKernelGGL(hrt_launch_dirs_kernel, dim3((uint32_t)((num_local + 255) / 256)), dim3(256),
+                       0, (hipStream_t)stream, num_paths, rank, count, chunk, num_local, d_dirs,
+                       d_fix_count, d_fix_list, fix_cap);
     return (int)hipGetLastError();
 }
 

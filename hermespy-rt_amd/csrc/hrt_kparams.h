@@ -63,6 +63,9 @@ int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_scan(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
+                        uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
+                        uint32_t *d_fix_list, uint32_t fix_cap, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
 int hrt_hip_read_stats(unsigned long long *out24, int reset);
 /* events: opaque handles */

@@ -21,7 +21,8 @@ from . import lib as _lib
 
 class Tracer:
     def __init__(self, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
-                 num_bounces, rank=0, world=1, chunk=0, device=None, host_threads=0, coherent=True):
+                 num_bounces, rank=0, world=1, chunk=0, device=None, host_threads=0, coherent=True,
+                 device_dirs=False):
         import torch  # torch first: its HIP runtime is the one the library binds to
 
         if not torch.cuda.is_available():
@@ -57,11 +58,25 @@ class Tracer:
                    "hrt_layout_query")
         self.cap = int(self.layout.cap)
 
-        # launch directions of this shard: host libm (bit-identical to the reference), once
-        dirs = np.empty((self.num_local, 3), np.float32)
-        _lib.check(self.L.hrt_launch_dirs_host(
-            C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)), host_threads),
-            "hrt_launch_dirs_host")
+        # launch directions of this shard, once: host libm (bit-identical to the reference by
+        # construction), or generated on the device with the host patching the few values whose
+        # float rounding could depend on the math library (bit-identical too; see hrt_device.h)
+        self.dirs_patched = None
+        if device_dirs:
+            with torch.cuda.device(self.device):
+                self.dirs = torch.empty((self.num_local, 3), dtype=torch.float32, device=self.device)
+            n_p = C.c_uint64(0)
+            _lib.check(self.L.hrt_launch_dirs_device(
+                C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()), self.device.index,
+                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.byref(n_p)),
+                "hrt_launch_dirs_device")
+            self.dirs_patched = int(n_p.value)
+            dirs = None
+        else:
+            dirs = np.empty((self.num_local, 3), np.float32)
+            _lib.check(self.L.hrt_launch_dirs_host(
+                C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)), host_threads),
+                "hrt_launch_dirs_host")
         self.dirs_host = dirs
         # coherent launch order: a wave = a narrow ray packet (speed only; results are keyed
         # by ray id)
@@ -69,11 +84,12 @@ class Tracer:
         if coherent:
             order = np.empty(self.num_local, np.uint32)
             _lib.check(self.L.hrt_launch_order_host(
-                C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)),
+                C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)) if dirs is not None else None,
                 order.ctypes.data_as(C.POINTER(C.c_uint32))), "hrt_launch_order_host")
             self.order_host = order
         with torch.cuda.device(self.device):
-            self.dirs = torch.from_numpy(dirs).to(self.device)
+            if dirs is not None:
+                self.dirs = torch.from_numpy(dirs).to(self.device)
             self.order = (torch.from_numpy(self.order_host.view(np.int32)).to(self.device)
                           if coherent else None)
             self.ws = torch.empty(int(self.layout.total_bytes), dtype=torch.uint8, device=self.device)

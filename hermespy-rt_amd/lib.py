@@ -16,7 +16,7 @@ EXPORTED = (
     "hrt_version", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
-    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_layout_query", "hrt_trace",
+    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_layout_query", "hrt_trace",
     "hrt_work_from_counts", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
     "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
     "hrt_selftest_math", "hrt_debug_kernel_stats", "hrt_scene_import_sionna",
@@ -110,6 +110,8 @@ def load():
     L.hrt_layout_query.restype = C.c_int
     L.hrt_launch_order_host.argtypes = [C.POINTER(Shard), f32p, C.POINTER(u32)]
     L.hrt_launch_order_host.restype = C.c_int
+    L.hrt_launch_dirs_device.argtypes = [C.POINTER(Shard), vp, C.c_int, vp, C.POINTER(u64)]
+    L.hrt_launch_dirs_device.restype = C.c_int
     L.hrt_trace.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, C.POINTER(KernelTimes)]
     L.hrt_trace.restype = C.c_int
     L.hrt_work_from_counts.argtypes = [vp, C.POINTER(Shard), C.POINTER(u32), C.POINTER(Stats)]

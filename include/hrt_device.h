@@ -68,11 +68,21 @@ uint64_t hrt_shard_global_path(const hrt_shard *s, uint64_t local_i);
  * cores. */
 int hrt_launch_dirs_host(const hrt_shard *s, float *out, int num_threads);
 
+/* The same directions generated ON THE DEVICE into d_dirs (device [num_local][3] floats),
+ * bit-identical to hrt_launch_dirs_host: the device evaluates the reference's formula with its
+ * own double math library and flags every value whose rounding to float could depend on that
+ * library's last bits (closer than 2^-44 relative to a float rounding boundary; about one ray
+ * in a million); the flagged rays are recomputed with the host libm and patched in.  Blocks
+ * until done; *num_patched (may be NULL) returns how many rays were patched. */
+int hrt_launch_dirs_device(const hrt_shard *s, float *d_dirs, int device, void *stream,
+                           uint64_t *num_patched);
+
 /* Coherent launch order of this shard: a permutation of 0..num_local-1 (order[i] = local ray
  * launched by lane i) that walks the sphere in z-bands, serpentine in azimuth, so that 64
  * consecutive lanes -- one wavefront -- form a narrow ray packet (what the packet culling of
- * the bounce kernel feeds on).  Pure function of `dirs` ([num_local][3], from
- * hrt_launch_dirs_host).  Results do not depend on the order (records carry ray ids); only
+ * the trace kernel feeds on).  Pure function of `dirs` ([num_local][3], from
+ * hrt_launch_dirs_host); dirs == NULL derives the keys from the path indices alone (for
+ * directions generated on the device).  Results do not depend on the order (records carry ray ids); only
  * speed does. */
 int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order_out);
 
