@@ -317,19 +317,16 @@ __device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid,
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
-// upper / lower bound of d.G over the cone (|d| = 1)
-__device__ __forceinline__ void cone_range(const Packet &P, F3 G, float &lo, float &hi)
+// upper bound of d.G over the cone (|d| = 1); the lower bound is -cone_upper(-G)
+__device__ __forceinline__ float cone_upper(const Packet &P, F3 G)
 {
     const float g2 = dot3(G, G);
-    const float ig = (g2 > 1e-30f) ? fast_rsq(g2) : 0.f;
-    const float g = g2 * ig;
-    const float c = fminf(1.f, fmaxf(-1.f, dot3(P.ax, G) * ig));
-    const float s = fast_sqrt(fmaxf(0.f, 1.f - c * c));
-    hi = (c >= P.cosa) ? g : g * (c * P.cosa + s * P.sina);
-    lo = (c <= -P.cosa) ? -g : g * (c * P.cosa - s * P.sina);
-    const float slack = 1e-4f * g;
-    hi += slack;
-    lo -= slack;
+    const float c1 = dot3(P.ax, G);                      // g cos(beta)
+    const float s1 = fast_sqrt(fmaxf(0.f, g2 - c1 * c1));   // g sin(beta)
+    const float g = fast_sqrt(g2);
+    // inside the cone (beta <= alpha): the maximum is g itself
+    const float hi = (c1 >= g * P.cosa) ? g : (c1 * P.cosa + s1 * P.sina);
+    return hi + 1e-4f * g;
 }
 
 // true iff triangle row (q0,q1,q2) with lengths L = (|e1|, |e2|, |e2-e1|, |N|) is provably
@@ -349,27 +346,25 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const float dn = dot3(P.ax, nh);
     // all rays on one side of the plane's direction field, so sigma is constant
     if (!(L.w * (fabsf(dn) * P.cosa - P.sina) > 3.f * Ed + 1e-30f)) return false;
-    const bool pos = dn < 0.f;   // sigma = sign(det) = sign(-d.N) = +1
+    // sigma = sign(det) = sign(-d.N): work with sigma*G so that only UPPER bounds are needed
+    const float sg = (dn < 0.f) ? 1.f : -1.f;
     const float Eu = kE * S * L.y, Ev = kE * S * L.x, Et = kE * S * L.x * L.y;
     const float aN = L.w * 1.0001f + Ed;
     const float tol_u = 2.f * (2.f * kEps * aN + Eu);
     const float tol_v = 2.f * (2.f * kEps * aN + Ev);
-    const float tol_w = 2.f * (4.f * kEps * aN + Eu + Ev + Ed);
-    // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - ro, h + ro]
+    // N = e1 x e2 is taken as n * |N| (table values, ~2e-7 relative): covered by 4e-6 |N| in tol_w
+    const float tol_w = 2.f * (4.f * kEps * aN + Eu + Ev + Ed) + 4e-6f * L.w;
+    // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - br, h + br]
     const float h = dot3(sb, nh);
-    const float snt_max = pos ? (h + P.br) : -(h - P.br);   // divided by |N|
+    const float snt_max = sg * h + P.br;   // divided by |N|
     bool cull = snt_max * L.w < -2.f * Et - 1e-4f * L.w * (fabsf(h) + P.br);
-    const F3 Gu = cross3(e2, sc);
-    const F3 Gv = cross3(sc, e1);
-    const F3 Nn = cross3(e1, e2);
-    const F3 Gw = add3(add3(Gu, Gv), Nn);
-    float lo, hi;
-    cone_range(P, Gu, lo, hi);
-    cull |= ((pos ? hi : -lo) + L.y * P.ro * 1.0001f) < -tol_u;
-    cone_range(P, Gv, lo, hi);
-    cull |= ((pos ? hi : -lo) + L.x * P.ro * 1.0001f) < -tol_v;
-    cone_range(P, Gw, lo, hi);
-    cull |= ((pos ? lo : -hi) - L.z * P.ro * 1.0001f) > tol_w;
+    const F3 Gu = mul3(cross3(e2, sc), sg);
+    const F3 Gv = mul3(cross3(sc, e1), sg);
+    const F3 Gw = add3(add3(Gu, Gv), mul3(nh, sg * L.w));
+    // max over the packet of sigma*Nu, sigma*Nv; min of sigma*(Nu+Nv-det) = -max of its negative
+    cull |= (cone_upper(P, Gu) + L.y * P.ro * 1.0001f) < -tol_u;
+    cull |= (cone_upper(P, Gv) + L.x * P.ro * 1.0001f) < -tol_v;
+    cull |= (cone_upper(P, {-Gw.x, -Gw.y, -Gw.z}) + L.z * P.ro * 1.0001f) < -tol_w;
     return cull;
 }
 
