@@ -200,11 +200,13 @@ def main():
             gather_err = "init: %r" % (e,)
     in_step = gather is not None and args.gather_in_step
 
-    def step(timed):
-        t = tr.trace(timed=timed)
+    def step(timer=None):
+        if timer is None:
+            tr.trace()
+        else:
+            tr.trace_with_timer(timer)   # HIP events around every kernel, no host sync
         if in_step:
             gather.run()
-        return t
 
     if args.calibrate:
         import ctypes
@@ -216,19 +218,17 @@ def main():
         _l.check(_l.load().hrt_selftest_math(local_rank, 1, x.ctypes.data_as(f32p), y.ctypes.data_as(f32p), n))
 
     for _ in range(args.warmup):
-        step(False)
+        step()
+    # one timer (set of HIP events) per timed step: recorded on the launch stream inside the
+    # timed region, read after it -- the steps themselves run back to back, asynchronously
+    timers = [tr.new_timer() for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    bounce_ms, los_ms, compact_ms, shade_ms = [], [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lm, bm = step(True)   # HIP events around every launch, on the launch stream
-        los_ms.append(lm)
-        bounce_ms.append(bm)
-        compact_ms.append(sum(tr.last_compact_ms))
-        shade_ms.append(tr.last_shade_ms)
+    for k in range(args.steps):
+        step(timers[k])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -236,6 +236,13 @@ def main():
     dt = time.perf_counter() - t0
     t_all = xreduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
     dt = float(t_all.item())
+    bounce_ms, los_ms, compact_ms, shade_ms = [], [], [], []
+    for t in timers:
+        r = tr.read_timer(t)
+        los_ms.append(r["los_ms"])
+        bounce_ms.append(r["trace_ms"])
+        shade_ms.append(r["shade_ms"])
+        compact_ms.append(sum(r["scan_ms"]))
 
     # ---- the collection step, measured on its own (N > 1) ----
     gather_info = None

@@ -459,9 +459,87 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     return HRT_OK;
 }
 
+struct hrt_timer {
+    uint32_t num_bounces;
+    int recorded;
+    void *ev[2 + 4 * 34];
+};
+
+int hrt_timer_create(uint32_t num_bounces, hrt_timer **out)
+{
+    if (!out || num_bounces == 0 || num_bounces > 32) return hrt_fail(HRT_E_INVALID, "hrt_timer_create: bad argument");
+    hrt_timer *t = (hrt_timer *)calloc(1, sizeof *t);
+    if (!t) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    t->num_bounces = num_bounces;
+    const uint32_t n = 2 + 4 * (num_bounces + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc = hrt_hip_event_create(&t->ev[i]);
+        if (rc) {
+            for (uint32_t k = 0; k < i; ++k) hrt_hip_event_destroy(t->ev[k]);
+            free(t);
+            return hrt_fail_hip(rc, "hipEventCreate");
+        }
+    }
+    *out = t;
+    return HRT_OK;
+}
+
+void hrt_timer_destroy(hrt_timer *t)
+{
+    if (!t) return;
+    for (uint32_t i = 0; i < 2 + 4 * (t->num_bounces + 1); ++i) hrt_hip_event_destroy(t->ev[i]);
+    free(t);
+}
+
+int hrt_timer_read(hrt_timer *t, hrt_kernel_times *times)
+{
+    if (!t || !times || !t->recorded) return hrt_fail(HRT_E_INVALID, "hrt_timer_read: nothing recorded");
+    const uint32_t nb = t->num_bounces;
+    memset(times, 0, sizeof *times);
+    int hip = hrt_hip_event_sync(t->ev[5 + 4 * nb]);
+#define STEP(call) do { if (!hip) hip = (call); } while (0)
+    STEP(hrt_hip_event_elapsed_ms(t->ev[0], t->ev[1], &times->los_ms));
+    for (uint32_t b = 0; b <= nb && !hip; ++b) {
+        STEP(hrt_hip_event_elapsed_ms(t->ev[2 + 4 * b], t->ev[3 + 4 * b], &times->trace_ms[b]));
+        STEP(hrt_hip_event_elapsed_ms(t->ev[3 + 4 * b], t->ev[4 + 4 * b], &times->compact_ms[b]));
+        STEP(hrt_hip_event_elapsed_ms(t->ev[4 + 4 * b], t->ev[5 + 4 * b], &times->shade_ms[b]));
+    }
+#undef STEP
+    times->num_bounce_launches = nb + 1;
+    if (hip) return hrt_fail_hip(hip, "hrt_timer_read");
+    return HRT_OK;
+}
+
+static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+                      const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
+                      hrt_timer *timer);
+
 int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
               const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
               hrt_kernel_times *times)
+{
+    if (!times) return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, NULL);
+    if (!s) return hrt_fail(HRT_E_INVALID, "hrt_trace: NULL argument");
+    hrt_timer *t = NULL;
+    int rc = hrt_timer_create(s->num_bounces, &t);
+    if (rc) return rc;
+    rc = trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, t);
+    if (!rc) rc = hrt_timer_read(t, times);
+    hrt_timer_destroy(t);
+    return rc;
+}
+
+int hrt_trace_timed(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+                    const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
+                    hrt_timer *timer)
+{
+    if (!timer) return hrt_fail(HRT_E_INVALID, "hrt_trace_timed: NULL timer");
+    return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, timer);
+}
+
+static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+                      const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
+                      hrt_timer *timer)
 {
     if (!p || !d_dirs || !d_ws) return hrt_fail(HRT_E_INVALID, "hrt_trace: NULL argument");
     hrt_layout L;
@@ -495,45 +573,28 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
 
     HRT_HIP(hrt_hip_set_device(p->device), "hipSetDevice");
     const uint32_t nb = s->num_bounces;
-    /* events: [0,1] around LoS; per launch b: start, end of trace (= start of scan), end of
-     * scan (= start of shade), end of shade */
-    void *ev[2 + 4 * 34] = {0};
-    const uint32_t n_ev = times ? 2 + 4 * (nb + 1) : 0;
-    for (uint32_t i = 0; i < n_ev; ++i) {
-        rc = hrt_hip_event_create(&ev[i]);
-        if (rc) {
-            for (uint32_t k = 0; k < i; ++k) hrt_hip_event_destroy(ev[k]);
-            return hrt_fail_hip(rc, "hipEventCreate");
-        }
-    }
+    /* events (only with a timer): [0,1] around LoS; per launch b: start, end of trace (= start
+     * of scan), end of scan (= start of shade), end of shade */
+    void **ev = timer ? timer->ev : NULL;
+    if (timer && timer->num_bounces != nb)
+        return hrt_fail(HRT_E_INVALID, "timer was created for %u bounces, trace has %u", timer->num_bounces, nb);
     int hip = 0;
 #define STEP(call) do { if (!hip) hip = (call); } while (0)
     STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0, (nb + 2) * 4, stream));
-    if (times) STEP(hrt_hip_event_record(ev[0], stream));
+    if (ev) STEP(hrt_hip_event_record(ev[0], stream));
     STEP(hrt_hip_launch_los(&K, stream));
-    if (times) STEP(hrt_hip_event_record(ev[1], stream));
+    if (ev) STEP(hrt_hip_event_record(ev[1], stream));
     for (uint32_t b = 0; b <= nb; ++b) {
-        if (times) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
+        if (ev) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
         STEP(hrt_hip_launch_trace(&K, b, stream));
-        if (times) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
+        if (ev) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
         if (b < nb) STEP(hrt_hip_launch_scan(&K, b, stream));
-        if (times) STEP(hrt_hip_event_record(ev[4 + 4 * b], stream));
+        if (ev) STEP(hrt_hip_event_record(ev[4 + 4 * b], stream));
         STEP(hrt_hip_launch_shade(&K, b, stream));
-        if (times) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
-    }
-    if (times && !hip) {
-        STEP(hrt_hip_stream_sync(stream));
-        memset(times, 0, sizeof *times);
-        if (!hip) STEP(hrt_hip_event_elapsed_ms(ev[0], ev[1], &times->los_ms));
-        for (uint32_t b = 0; b <= nb && !hip; ++b) {
-            STEP(hrt_hip_event_elapsed_ms(ev[2 + 4 * b], ev[3 + 4 * b], &times->trace_ms[b]));
-            STEP(hrt_hip_event_elapsed_ms(ev[3 + 4 * b], ev[4 + 4 * b], &times->compact_ms[b]));
-            STEP(hrt_hip_event_elapsed_ms(ev[4 + 4 * b], ev[5 + 4 * b], &times->shade_ms[b]));
-        }
-        times->num_bounce_launches = nb + 1;
+        if (ev) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
     }
 #undef STEP
-    for (uint32_t i = 0; i < n_ev; ++i) hrt_hip_event_destroy(ev[i]);
+    if (timer) timer->recorded = !hip;
     if (hip) return hrt_fail_hip(hip, "hrt_trace");
     return HRT_OK;
 }

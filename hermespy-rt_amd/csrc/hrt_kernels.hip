@@ -1276,6 +1276,7 @@ int hrt_hip_event_record(void *ev, void *stream)
 {
     return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
 }
+int hrt_hip_event_sync(void *ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
 int hrt_hip_event_elapsed_ms(void *start, void *stop, float *ms)
 {
     return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);

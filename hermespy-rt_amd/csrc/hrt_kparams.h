@@ -73,6 +73,7 @@ int hrt_hip_event_create(void **ev);
 int hrt_hip_event_destroy(void *ev);
 int hrt_hip_event_record(void *ev, void *stream);
 int hrt_hip_event_elapsed_ms(void *start, void *stop, float *ms);
+int hrt_hip_event_sync(void *ev);
 const char *hrt_hip_error_string(int err);
 
 #ifdef __cplusplus

@@ -128,6 +128,33 @@ class Tracer:
             return self.last_times
         return None
 
+    # ------------------------------------------------------------------ deferred timing
+    def new_timer(self):
+        t = C.c_void_p()
+        _lib.check(self.L.hrt_timer_create(self.nb, C.byref(t)), "hrt_timer_create")
+        return t
+
+    def trace_with_timer(self, timer):
+        """Like trace(): asynchronous; HIP events around every kernel go into `timer`."""
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.L.hrt_trace_timed(
+            self.problem, C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()),
+            C.c_void_p(self.order.data_ptr()) if self.order is not None else None,
+            C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream), timer),
+            "hrt_trace_timed")
+
+    def read_timer(self, timer, destroy=True):
+        """-> dict(los_ms, trace_ms[], shade_ms[], scan_ms[]); waits for the timer's last event."""
+        times = _lib.KernelTimes()
+        _lib.check(self.L.hrt_timer_read(timer, C.byref(times)), "hrt_timer_read")
+        n = int(times.num_bounce_launches)
+        out = dict(los_ms=float(times.los_ms), trace_ms=[float(times.trace_ms[i]) for i in range(n)],
+                   shade_ms=[float(times.shade_ms[i]) for i in range(n)],
+                   scan_ms=[float(times.compact_ms[i]) for i in range(n)])
+        if destroy:
+            self.L.hrt_timer_destroy(timer)
+        return out
+
     # ------------------------------------------------------------------ views
     def _view(self, off, n, dtype):
         t = self.ws[off:off + n * 4]

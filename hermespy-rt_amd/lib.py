@@ -17,7 +17,8 @@ EXPORTED = (
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
     "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_layout_query", "hrt_trace",
-    "hrt_work_from_counts", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
+    "hrt_work_from_counts", "hrt_timer_create", "hrt_timer_destroy", "hrt_trace_timed",
+    "hrt_timer_read", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
     "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
     "hrt_selftest_math", "hrt_debug_kernel_stats", "hrt_scene_import_sionna",
 )
@@ -114,6 +115,14 @@ def load():
     L.hrt_launch_dirs_device.restype = C.c_int
     L.hrt_trace.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, C.POINTER(KernelTimes)]
     L.hrt_trace.restype = C.c_int
+    L.hrt_timer_create.argtypes = [u32, C.POINTER(vp)]
+    L.hrt_timer_create.restype = C.c_int
+    L.hrt_timer_destroy.argtypes = [vp]
+    L.hrt_timer_destroy.restype = None
+    L.hrt_trace_timed.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, vp]
+    L.hrt_trace_timed.restype = C.c_int
+    L.hrt_timer_read.argtypes = [vp, C.POINTER(KernelTimes)]
+    L.hrt_timer_read.restype = C.c_int
     L.hrt_work_from_counts.argtypes = [vp, C.POINTER(Shard), C.POINTER(u32), C.POINTER(Stats)]
     L.hrt_work_from_counts.restype = None
     L.hrt_device_count.argtypes = [C.POINTER(C.c_int)]

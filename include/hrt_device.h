@@ -168,6 +168,18 @@ int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
               const uint32_t *d_order, void *d_workspace, uint64_t workspace_bytes, void *stream,
               hrt_kernel_times *times);
 
+/* Per-kernel timing WITHOUT a synchronisation per call: a timer owns the HIP events of one
+ * hrt_trace; hrt_trace_timed records them on `stream` and returns at once (asynchronous, like
+ * hrt_trace with times == NULL); hrt_timer_read waits for the timer's last event and converts.
+ * Use one timer per call in flight (bench.py: one per timed step, read after the timed region). */
+typedef struct hrt_timer hrt_timer;
+int hrt_timer_create(uint32_t num_bounces, hrt_timer **out);
+void hrt_timer_destroy(hrt_timer *t);
+int hrt_trace_timed(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+                    const uint32_t *d_order, void *d_workspace, uint64_t workspace_bytes,
+                    void *stream, hrt_timer *timer);
+int hrt_timer_read(hrt_timer *t, hrt_kernel_times *out);
+
 /* Algorithmic work of a finished trace from its (host copy of) counts: see hrt_stats. */
 void hrt_work_from_counts(const hrt_problem *p, const hrt_shard *s, const uint32_t *counts,
                           hrt_stats *out);
