@@ -224,30 +224,112 @@ __device__ unsigned long long g_stats[3][8];
 #endif
 
 // Wave-wide reductions on the VALU only (DPP row shifts + row broadcasts, the GCN/CDNA
-// reduction idiom): 6 DPP ops, no LDS traffic, result read from lane 63 into an SGPR, i.e.
-// wave-uniform.  All 64 lanes must be active (callers run in uniform control flow).
-#define HRT_DPP(old_, src_, ctrl_, rowmask_)                                                     \
-    __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(old_),           \
-                                                          (int)__float_as_uint(src_), ctrl_,    \
-                                                          rowmask_, 0xf, false))
-struct OpMin { static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); } };
-struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
-struct OpAdd { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
-
-template <typename Op>
-__device__ __forceinline__ float wave_reduce(float v, const float ident)
+// reduction idiom), written as inline assembly: ONE in-place instruction per step
+// (`v_min_f32_dpp v, v, v row_shr:1`: lanes whose DPP source is out of range are not written and
+// keep their own value, which is the identity of min/max/add-of-nothing), where the builtin
+// route costs four (identity v_mov, v_mov_dpp, a NaN-canonicalising v_max, the operation) plus
+// a hazard s_nop.  Several independent chains are interleaved step by step so that the two wait
+// states a DPP read needs after the VALU write of its source are filled with work, not s_nops.
+// The total ends in lane 63 and is read into an SGPR, i.e. wave-uniform.  All 64 lanes must be
+// active (callers run in uniform control flow); inputs must not be NaN.  (The leading s_nop 4
+// covers the worst hazard in front of a DPP instruction -- 5 wait states after a VALU write of
+// EXEC -- since the compiler's hazard recogniser does not look inside inline assembly.)
+__device__ __forceinline__ float lane63(float v)
 {
-    v = Op::f(v, HRT_DPP(ident, v, 0x111, 0xf));   // row_shr:1
-    v = Op::f(v, HRT_DPP(ident, v, 0x112, 0xf));   // row_shr:2
-    v = Op::f(v, HRT_DPP(ident, v, 0x114, 0xf));   // row_shr:4
-    v = Op::f(v, HRT_DPP(ident, v, 0x118, 0xf));   // row_shr:8   -> lane 15 of each row: row total
-    v = Op::f(v, HRT_DPP(ident, v, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
-    v = Op::f(v, HRT_DPP(ident, v, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
-__device__ __forceinline__ float wave_min_f(float v) { return wave_reduce<OpMin>(v, 3.0e38f); }
-__device__ __forceinline__ float wave_max_f(float v) { return wave_reduce<OpMax>(v, -3.0e38f); }
-__device__ __forceinline__ float wave_sum_f(float v) { return wave_reduce<OpAdd>(v, 0.f); }
+
+// component-wise minimum of lo and maximum of hi over the wave
+__device__ __forceinline__ void wave_min3_max3(F3 &lo, F3 &hi)
+{
+    asm volatile(
+        "s_nop 4\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_min_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_min_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_max_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_max_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_min_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_min_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_max_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_max_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_max_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
+    lo = {lane63(lo.x), lane63(lo.y), lane63(lo.z)};
+    hi = {lane63(hi.x), lane63(hi.y), lane63(hi.z)};
+}
+
+__device__ __forceinline__ F3 wave_sum3(F3 v)
+{
+    asm volatile(
+        "s_nop 4\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        : "+v"(v.x), "+v"(v.y), "+v"(v.z));
+    return {lane63(v.x), lane63(v.y), lane63(v.z)};
+}
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    asm volatile(
+        "s_nop 4\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(v));
+    return lane63(v);
+}
 
 struct Ball { F3 c; float r; bool ok; };   // bounding ball of the packet's ray origins
 
@@ -265,9 +347,10 @@ struct Packet {
 __device__ __forceinline__ Ball origin_ball(F3 o, bool valid)
 {
     const float big = 3.0e38f;
-    const float lox = wave_min_f(valid ? o.x : big), hix = wave_max_f(valid ? o.x : -big);
-    const float loy = wave_min_f(valid ? o.y : big), hiy = wave_max_f(valid ? o.y : -big);
-    const float loz = wave_min_f(valid ? o.z : big), hiz = wave_max_f(valid ? o.z : -big);
+    F3 lo = {valid ? o.x : big, valid ? o.y : big, valid ? o.z : big};
+    F3 hi = {valid ? o.x : -big, valid ? o.y : -big, valid ? o.z : -big};
+    wave_min3_max3(lo, hi);
+    const float lox = lo.x, loy = lo.y, loz = lo.z, hix = hi.x, hiy = hi.y, hiz = hi.z;
     Ball B;
     B.c = {0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz)};
     const F3 ext = {hix - lox, hiy - loy, hiz - loz};
@@ -297,8 +380,7 @@ __device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid,
         P.oc = B.c;
         P.ro = B.r;
     }
-    const F3 sd = {wave_sum_f(valid ? d.x : 0.f), wave_sum_f(valid ? d.y : 0.f),
-                   wave_sum_f(valid ? d.z : 0.f)};
+    const F3 sd = wave_sum3({valid ? d.x : 0.f, valid ? d.y : 0.f, valid ? d.z : 0.f});
     const float n2 = dot3(sd, sd);
     const float inv = 1.f / sqrtf(fmaxf(n2, 1e-30f));
     P.ax = {sd.x * inv, sd.y * inv, sd.z * inv};
