@@ -361,19 +361,20 @@ __device__ __forceinline__ Ball origin_ball(F3 o, bool valid)
     return B;
 }
 
-// Direction cone of the packet.  `apex` != nullptr: every ray was aimed at that point (shadow
+// Direction cone of the packet.  `shadow`: every ray was aimed at the point `apex` (shadow
 // rays towards an RX): numerators Nu, Nv, Nu+Nv-det and det are invariants of the ray LINE,
 // and the line of a ray built as normalise(apex - o) passes within 4u*L of apex (componentwise
 // rounding of the subtraction and the division), so the edge tests use the apex as the common
 // line point with that tiny radius instead of the origins' bounding ball.
-__device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid, const F3 *apex)
+__device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid, const bool shadow,
+                                                F3 apex)
 {
     Packet P;
     P.bc = B.c;
     P.br = B.r;
-    if (apex) {
-        P.oc = *apex;
-        const F3 v = sub3(*apex, B.c);
+    if (shadow) {
+        P.oc = apex;
+        const F3 v = sub3(apex, B.c);
         const float lmax = sqrtf(dot3(v, v)) * 1.00001f + B.r;
         P.ro = 8.f * (0.5f * kEps) * lmax + 1e-7f;
     } else {
@@ -522,13 +523,14 @@ constexpr uint32_t kMaskRounds = 16;
 template <typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, F3 o, F3 d,
                                                   bool valid, uint32_t lane, const Ball &B,
-                                                  const F3 *apex, unsigned long long *wmask,
+                                                  const bool shadow, F3 apex,
+                                                  unsigned long long *wmask,
                                                   [[maybe_unused]] int kind)
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
     {
-        const Packet P = packet_bounds(B, d, valid, apex);
+        const Packet P = packet_bounds(B, d, valid, shadow, apex);
         HRT_STAT(kind, 0, 1);
         HRT_STAT(kind, 1, P.usable ? 1 : 0);
         if (!P.usable) {
@@ -573,8 +575,8 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
 // ray and their result is meaningless.
 template <int VARIANT, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F3 d, bool valid,
-                                           uint32_t lane, const Ball &B, const F3 *apex,
-                                           unsigned long long *wmask, int kind)
+                                           uint32_t lane, const Ball &B, const bool shadow,
+                                           F3 apex, unsigned long long *wmask, int kind)
 {
     if constexpr (VARIANT == 0) {
         Hit h = {HRT_NO_HIT, 1e9f};
@@ -585,7 +587,7 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F
         if (valid) h = closest_hit_staged(tri, num_tri, o, d);
         return h;
     } else {
-        return closest_hit_packet(tri, num_tri, o, d, valid, lane, B, apex, wmask, kind);
+        return closest_hit_packet(tri, num_tri, o, d, valid, lane, B, shadow, apex, wmask, kind);
     }
 }
 
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     const uint32_t k_lo = first ? P.num_rx : 0u;
     const uint32_t k_hi = (b < P.num_bounces) ? P.num_rx + 1u : P.num_rx;
     const uint32_t kinds = k_hi - k_lo;
-    const uint64_t n_units = (uint64_t)n_chunks * kinds;
+    const uint32_t n_units = n_chunks * kinds;   // < 2^32: at most 2^24 chunks x 33 kinds
     if (blockIdx.x >= n_units) return;
 
     const uint32_t T = P.num_tri;
@@ -780,11 +782,12 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     }();
     const uint32_t lane = tid & 63u;
 
-    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-        const uint32_t chunk = (uint32_t)(unit / kinds);
-        const uint32_t k = k_lo + (uint32_t)(unit - (uint64_t)chunk * kinds);
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t chunk = unit / kinds;
+        const uint32_t k = k_lo + (unit - chunk * kinds);
         const uint32_t i = chunk * HRT_BLOCK + tid;
         const bool valid = i < n_in;
+        const bool shadow = k < P.num_rx;
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
         if (valid) {
             if (first) {
@@ -794,12 +797,11 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
                 const uint32_t pb = b - 1;
                 o = {hit_field(P, pb, H_OX)[i], hit_field(P, pb, H_OY)[i],
                      hit_field(P, pb, H_OZ)[i]};
-                if (k == P.num_rx)
+                if (!shadow)
                     d = {hit_field(P, pb, H_DX)[i], hit_field(P, pb, H_DY)[i],
                          hit_field(P, pb, H_DZ)[i]};
             }
         }
-        const bool shadow = k < P.num_rx;
         F3 apex = {0.f, 0.f, 0.f};
         if (shadow) {
             const float4 rp = l_rx[k];
@@ -810,8 +812,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
         }
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
         if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
-        const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball,
-                                           shadow ? &apex : nullptr, l_mask,
+        const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball, shadow, apex, l_mask,
                                            shadow ? 2 : (first ? 0 : 1));
         if (valid) {
             res_tri(P, k)[i] = h.tri;
