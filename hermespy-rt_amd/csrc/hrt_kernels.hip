@@ -470,7 +470,12 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     return cull;
 }
 
-// one staged test of triangle j for every lane; `rej0` lanes do not participate
+// One staged test of triangle J for every lane of the packet walk.  The certain-reject state is
+// kept as a 64-bit LANE MASK in SGPRs: each ballot of a single comparison is one v_cmp writing an
+// SGPR pair, the ORs and the "every lane rejected?" test are scalar instructions (a ballot of an
+// OR of comparisons costs two extra VALU instructions per stage).  All 64 lanes are active here;
+// `inval` has the bits of the lanes that carry no ray.
+#define HRT_BALLOT(c) __builtin_amdgcn_ballot_w64(c)
 #define HRT_STAGED_BODY(J)                                                                      \
     {                                                                                           \
         const float4 q0 = tri[HRT_ROW * (J)], q1 = tri[HRT_ROW * (J) + 1], q2 = tri[HRT_ROW * (J) + 2];           \
@@ -485,24 +490,26 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
         const uint32_t sg = __float_as_uint(det) & 0x80000000u;                                 \
         const float nu_s = xor_sign(nu, sg);                                                    \
         const float k1a = kK1 * a, k2a = kK2 * a;                                               \
-        bool rej = !valid | (a < kEps) | (nu_s < -k1a) | (nu_s > k2a);                          \
-        if (!wave_all(rej)) {                                                                   \
+        unsigned long long rm = inval | HRT_BALLOT(a < kEps) | HRT_BALLOT(nu_s < -k1a) |        \
+                                HRT_BALLOT(nu_s > k2a);                                         \
+        if (rm != ~0ull) {                                                                      \
             HRT_STAT(kind, 3, 1);                                                               \
             const F3 q = cross3(s, e1);                                                         \
             const float nv = dot3(d, q);                                                        \
             const float nv_s = xor_sign(nv, sg);                                                \
-            rej |= (nv_s < -k1a) | ((nu_s + nv_s) > kK3 * a);                                   \
-            if (!wave_all(rej)) {                                                               \
+            rm |= HRT_BALLOT(nv_s < -k1a) | HRT_BALLOT((nu_s + nv_s) > kK3 * a);                \
+            if (rm != ~0ull) {                                                                  \
                 HRT_STAT(kind, 4, 1);                                                           \
                 const float nt = dot3(e2, q);                                                   \
                 const float nt_s = xor_sign(nt, sg);                                            \
-                rej |= (nt_s < kK5 * a) | (nt_s > (best * a) * kK2);                            \
-                if (!wave_all(rej)) {                                                           \
+                rm |= HRT_BALLOT(nt_s < kK5 * a) | HRT_BALLOT(nt_s > (best * a) * kK2);         \
+                if (rm != ~0ull) {                                                              \
                     HRT_STAT(kind, 5, 1);                                                       \
                     const float u = nu / det;                                                   \
                     const float v = nv / det;                                                   \
                     const float w = u + v;                                                      \
                     const float dist = nt / det;                                                \
+                    const bool rej = (rm >> lane) & 1ull;                                       \
                     const bool miss = (det > -kEps && det < kEps) | (u < -kEps) |               \
                                       (u > kOnePlusEps) | (v < -kEps) | (w > kOnePlusEps);      \
                     const bool take = !rej & !miss & (dist > kEps) & (dist < best);             \
@@ -529,6 +536,7 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
+    const unsigned long long inval = HRT_BALLOT(!valid);
     {
         const Packet P = packet_bounds(B, d, valid, shadow, apex);
         HRT_STAT(kind, 0, 1);
