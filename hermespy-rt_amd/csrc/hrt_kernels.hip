@@ -414,20 +414,27 @@ __device__ __forceinline__ F3 fcross3(F3 a, F3 b)
             __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
 }
 
-// upper bound of d.G over the cone (|d| = 1); the lower bound is -cone_upper(-G)
-__device__ __forceinline__ float cone_upper(const Packet &P, F3 G)
+// upper bounds of d.G (hp) and of -d.G (hm) over the cone (|d| = 1)
+__device__ __forceinline__ void cone_bounds(const Packet &P, F3 G, float &hp, float &hm)
 {
     const float g2 = fdot3(G, G);
     const float c1 = fdot3(P.ax, G);                                       // g cos(beta)
     const float s1 = fast_sqrt(fmaxf(0.f, __builtin_fmaf(-c1, c1, g2)));   // g sin(beta)
     const float g = fast_sqrt(g2);
-    // inside the cone (beta <= alpha): the maximum is g itself
-    const float hi = (c1 >= g * P.cosa) ? g : __builtin_fmaf(c1, P.cosa, s1 * P.sina);
-    return __builtin_fmaf(1e-4f, g, hi);
+    const float gc = g * P.cosa, t1 = c1 * P.cosa, t2 = s1 * P.sina;
+    const float gs = __builtin_fmaf(1e-4f, g, g);
+    // axis within alpha of +-G: the maximum is g itself
+    hp = (c1 >= gc) ? gs : __builtin_fmaf(1e-4f, g, t2 + t1);
+    hm = (-c1 >= gc) ? gs : __builtin_fmaf(1e-4f, g, t2 - t1);
 }
 
 // true iff triangle row (q0,q1,q2) with lengths L = (|e1|, |e2|, |e2-e1|, |N|) is provably
-// rejected by the reference's test for every ray of the packet
+// rejected by the reference's test for every ray of the packet.  The acceptance conditions are
+// stated for sigma = sign(det_f), whatever it is: they are tested under BOTH hypotheses
+// sigma = +1 and sigma = -1 with the bounds of the whole cone, and the triangle is culled when
+// every hypothesis that is possible for some ray of the packet is rejected -- only one when
+// the cone does not straddle the triangle's plane, both otherwise (so triangles seen edge-on by
+// a wide packet are culled too, as long as they lie off to its side).
 __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 q1, float4 q2,
                                              float4 L)
 {
@@ -441,11 +448,9 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const F3 sc = sub3(P.oc, v1);
     const float Ed = kE * L.x * L.y;
     const float dn = fdot3(P.ax, nh);
-    // all rays on one side of the plane's direction field, so sigma is constant
-    if (!(L.w * __builtin_fmaf(fabsf(dn), P.cosa, -P.sina) > __builtin_fmaf(3.f, Ed, 1e-30f)))
-        return false;
-    // sigma = sign(det) = sign(-d.N): work with sigma*G so that only UPPER bounds are needed
-    const float sg = (dn < 0.f) ? 1.f : -1.f;
+    // all rays on one side of the plane's direction field: sigma = sign(det) = sign(-d.N) is known
+    const bool one_sided =
+        L.w * __builtin_fmaf(fabsf(dn), P.cosa, -P.sina) > __builtin_fmaf(3.f, Ed, 1e-30f);
     const float kS = kE * S;
     const float Eu = kS * L.y, Ev = kS * L.x, Et = Eu * L.x;
     const float aN = __builtin_fmaf(L.w, 1.0001f, Ed);
@@ -453,21 +458,30 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const float tol_v = 2.f * __builtin_fmaf(2.f * kEps, aN, Ev);
     // N = e1 x e2 is taken as n * |N| (table values, ~2e-7 relative): covered by 4e-6 |N| in tol_w
     const float tol_w = __builtin_fmaf(2.f, __builtin_fmaf(4.f * kEps, aN, Eu + Ev + Ed), 4e-6f * L.w);
-    // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - br, h + br]
+    // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - br, h + br] (divided by |N|)
     const float h = fdot3(sb, nh);
-    const float snt_max = __builtin_fmaf(sg, h, P.br);   // divided by |N|
-    bool cull = snt_max * L.w < __builtin_fmaf(-1e-4f * L.w, fabsf(h) + P.br, -2.f * Et);
-    const F3 Gu = mul3(fcross3(e2, sc), sg);
-    const F3 Gv = mul3(fcross3(sc, e1), sg);
-    const float nw = sg * L.w;
-    const F3 Gw = {__builtin_fmaf(nh.x, nw, Gu.x + Gv.x), __builtin_fmaf(nh.y, nw, Gu.y + Gv.y),
-                   __builtin_fmaf(nh.z, nw, Gu.z + Gv.z)};
-    // max over the packet of sigma*Nu, sigma*Nv; min of sigma*(Nu+Nv-det) = -max of its negative
+    const float thr = __builtin_fmaf(-1e-4f * L.w, fabsf(h) + P.br, -2.f * Et);
+    bool rej_p = (P.br + h) * L.w < thr;
+    bool rej_m = (P.br - h) * L.w < thr;
+    // Nu = d.Gu, Nv = d.Gv, Nu + Nv - det = d.Gw (+- |edge| ro for the spread of the line points)
+    const F3 Gu = fcross3(e2, sc);
+    const F3 Gv = fcross3(sc, e1);
+    const F3 Gw = {__builtin_fmaf(nh.x, L.w, Gu.x + Gv.x), __builtin_fmaf(nh.y, L.w, Gu.y + Gv.y),
+                   __builtin_fmaf(nh.z, L.w, Gu.z + Gv.z)};
     const float ro = P.ro * 1.0001f;
-    cull |= __builtin_fmaf(L.y, ro, cone_upper(P, Gu)) < -tol_u;
-    cull |= __builtin_fmaf(L.x, ro, cone_upper(P, Gv)) < -tol_v;
-    cull |= __builtin_fmaf(L.z, ro, cone_upper(P, {-Gw.x, -Gw.y, -Gw.z})) < -tol_w;
-    return cull;
+    float hp, hm;
+    // acceptance needs sigma*Nu >= -tol_u, sigma*Nv >= -tol_v, sigma*(Nu+Nv-det) <= tol_w
+    cone_bounds(P, Gu, hp, hm);
+    rej_p |= __builtin_fmaf(L.y, ro, hp) < -tol_u;
+    rej_m |= __builtin_fmaf(L.y, ro, hm) < -tol_u;
+    cone_bounds(P, Gv, hp, hm);
+    rej_p |= __builtin_fmaf(L.x, ro, hp) < -tol_v;
+    rej_m |= __builtin_fmaf(L.x, ro, hm) < -tol_v;
+    cone_bounds(P, Gw, hp, hm);
+    rej_p |= __builtin_fmaf(L.z, ro, hm) < -tol_w;
+    rej_m |= __builtin_fmaf(L.z, ro, hp) < -tol_w;
+    if (one_sided) return (dn < 0.f) ? rej_p : rej_m;
+    return rej_p & rej_m;
 }
 
 // One staged test of triangle J for every lane of the packet walk.  The certain-reject state is
