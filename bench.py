@@ -322,7 +322,7 @@ def main():
         from hermespy_rt_amd import lib as _l2
         arr = (ctypes.c_uint64 * 24)()
         if _l2.load().hrt_debug_kernel_stats(local_rank, arr, 0) == 0 and any(arr):
-            kstats = [[int(arr[k * 8 + j]) for j in range(6)] for k in range(3)]
+            kstats = [[int(arr[k * 8 + j]) for j in range(8)] for k in range(3)]
     except Exception:
         pass
     if rank == 0:
@@ -340,7 +340,7 @@ def main():
             work=dict(live=live, records=records, records_unblocked=unblk, tests=tests),
             roofline=roofline)
         if kstats:
-            out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
+            out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact", "heavy_packets", "heavy_candidates"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
         if gather_info:
             gms = gather_info["ms"]
             gather_info["GBps_into_root"] = gather_info["bytes_into_root"] / max(gms, 1e-9) / 1e6

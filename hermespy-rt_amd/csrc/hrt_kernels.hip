@@ -560,6 +560,9 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
             for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
             return {who, best};
         }
+#ifdef HRT_KERNEL_STATS
+        uint32_t ctot = 0;
+#endif
         for (uint32_t base = 0, r = 0; base < num_tri && r < kMaskRounds; base += 64u, ++r) {
             const uint32_t jl = base + lane;
             bool cand = false;
@@ -568,8 +571,15 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
                                      tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 4]);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
             HRT_STAT(kind, 2, __popcll(m));
+#ifdef HRT_KERNEL_STATS
+            ctot += (uint32_t)__popcll(m);
+#endif
             if (lane == 0) wmask[r] = m;
         }
+#ifdef HRT_KERNEL_STATS
+        HRT_STAT(kind, 6, ctot > 24u ? 1 : 0);
+        HRT_STAT(kind, 7, ctot > 24u ? ctot : 0);
+#endif
     }
     for (uint32_t base = 0, r = 0; base < num_tri && r < kMaskRounds; base += 64u, ++r) {
         // written by this wave's lane 0 above, read back by all its lanes: same wave, in order

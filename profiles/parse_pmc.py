@@ -16,7 +16,9 @@ TRUE_KIB = 131072.0   # bench.py --calibrate: 32 Mi floats read, 32 Mi floats wr
 
 raw = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(REPO, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv"))[0]
+    # gpurun merges results into gpurun_out/ without deleting older ones: take the newest
+    f = max(glob.glob(os.path.join(REPO, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv")),
+            key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if "hrt_" in r["Kernel_Name"]]
     keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
             "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
