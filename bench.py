@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--gather-in-step", action="store_true",
                     help="N > 1: run the RCCL gather of all records to rank 0 inside every timed step")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: do not measure the gather at all")
+    ap.add_argument("--gather-timeout", type=float, default=120.0,
+                    help="N > 1: give up on the gather measurement after this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--calibrate", action="store_true",
@@ -244,27 +246,6 @@ def main():
         shade_ms.append(r["shade_ms"])
         compact_ms.append(sum(r["scan_ms"]))
 
-    # ---- the collection step, measured on its own (N > 1) ----
-    gather_info = None
-    if gather is not None and not in_step:
-        try:
-            gather.run()                      # warm-up: allocates the receive buffers
-            torch.cuda.synchronize()
-            dist.barrier()
-            g0 = time.perf_counter()
-            n_g = 3
-            for _ in range(n_g):
-                gather.run()
-            torch.cuda.synchronize()
-            dist.barrier()
-            g_dt = xreduce(torch.tensor([(time.perf_counter() - g0) / n_g], dtype=torch.float64,
-                                        device=dev), dist.ReduceOp.MAX)
-            words = sum(sharding.export_words(gather.counts_all[r], tr.nb, tr.nrx)
-                        for r in range(world) if r != 0) if rank == 0 else 0
-            gather_info = dict(ms=float(g_dt.item()) * 1e3, bytes_into_root=int(words) * 4)
-        except Exception as e:
-            gather_err = "run: %r" % (e,)
-
     # ---- work done (identical every step) ----
     counts = tr.counts()
     w = tr.work(counts)
@@ -341,6 +322,47 @@ def main():
             roofline=roofline)
         if kstats:
             out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact", "heavy_packets", "heavy_candidates"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
+    else:
+        out = None
+
+    # ---- the collection step, measured on its own (N > 1), LAST and under a watchdog: the
+    # metric above is complete before the first collective of the gather is issued, and if the
+    # gather hangs (it cannot be rehearsed over real xGMI links on a one-GPU box) every rank
+    # leaves after `--gather-timeout` seconds and rank 0 still prints the line ----
+    gather_info = None
+    if gather is not None and not in_step:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["gather_error"] = "timeout after %.0f s" % args.gather_timeout
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.gather_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            gather.run()                      # warm-up: allocates the receive buffers
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            n_g = 3
+            for _ in range(n_g):
+                gather.run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            g_dt = xreduce(torch.tensor([(time.perf_counter() - g0) / n_g], dtype=torch.float64,
+                                        device=dev), dist.ReduceOp.MAX)
+            words = sum(sharding.export_words(gather.counts_all[r], tr.nb, tr.nrx)
+                        for r in range(world) if r != 0) if rank == 0 else 0
+            gather_info = dict(ms=float(g_dt.item()) * 1e3, bytes_into_root=int(words) * 4)
+        except Exception as e:
+            gather_err = "run: %r" % (e,)
+        dog.cancel()
+    if rank == 0:
         if gather_info:
             gms = gather_info["ms"]
             gather_info["GBps_into_root"] = gather_info["bytes_into_root"] / max(gms, 1e-9) / 1e6
@@ -350,12 +372,19 @@ def main():
             out["gather"] = gather_info
         if gather_err:
             out["gather_error"] = gather_err
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        dog2 = None
+        try:
+            import threading
+            dog2 = threading.Timer(60.0, lambda: os._exit(0))   # the line is out: never hang on teardown
+            dog2.daemon = True
+            dog2.start()
+            dist.barrier()
+            dist.destroy_process_group()
+        finally:
+            if dog2 is not None:
+                dog2.cancel()
 
 
 if __name__ == "__main__":
