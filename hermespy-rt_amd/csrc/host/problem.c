@@ -666,7 +666,7 @@ int hrt_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 
 int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t n)
 {
-    if (!in || !out || fn < 0 || fn > 4) return hrt_fail(HRT_E_INVALID, "hrt_selftest_math: bad argument");
+    if (!in || !out || fn < 0 || fn > 7) return hrt_fail(HRT_E_INVALID, "hrt_selftest_math: bad argument");
     void *d_in = NULL, *d_out = NULL;
     int rc = hrt_device_malloc(device, &d_in, n * 4);
     if (rc) return rc;

@@ -670,14 +670,14 @@ __device__ __forceinline__ void complex_div(float ar, float ai, float br, float 
 // the intersection loops (174 -> ~80 VGPRs: 2 -> 5+ waves per SIMD).
 __device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th)
 {
-    const float s1 = sin_f(th);
+    float s1, c1;
+    hrt_sincosf(th, &s1, &c1);   // sinf(th) and cosf(th) (:310, :325) from one reduction
     if (m2.z * s1 > 1.f - kEps) return make_float4(1.f, 0.f, 1.f, 0.f);
     const float s2 = s1 * s1;
     const float c2r = sqrtf(1.f + m0.z / m2.y * s2);
     const float c2i = sqrtf(1.f - m1.z / m2.y * s2);
     const float pr = m0.y * c2r - m1.y * c2i;
     const float pi = m0.y * c2i + m1.y * c2r;
-    const float c1 = cos_f(th);
     float4 R;
     complex_div(c1 - pr, -pi, c1 + pr, pi, R.x, R.y);
     const float qr = m0.y * c1;
@@ -690,7 +690,9 @@ __device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th
 // src/compute_paths.c:359-415; s = scattering coefficient, alpha = s1_alpha (small integer)
 __device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s, float th_i)
 {
-    const float cs = cos_f(th_s), ci = cos_f(th_i), si = sin_f(th_i);
+    const float cs = hrt_cosf_nb(th_s);
+    float si, ci;
+    hrt_sincosf(th_i, &si, &ci);
     const float dth = fabsf(th_s - th_i);
     const float f = s * exp_f(-alpha * dth);
     const float rough = 1.0f / (1.0f + alpha);
@@ -875,7 +877,10 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
 //            of the chunk's slice of the staging block, count to chunk_cnt).
 // LDS: [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts]
 // ===================================================================================
-__global__ __launch_bounds__(HRT_BLOCK) void hrt_shade_kernel(const hrt_kparams P,
+#ifndef HRT_SHADE_WAVES
+#define HRT_SHADE_WAVES 5   /* 96 VGPRs (8 dwords spilled): 5 waves/SIMD instead of 4, shade -5 % */
+#endif
+__global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(const hrt_kparams P,
                                                               const uint32_t b)
 {
     extern __shared__ float4 lds[];
@@ -1233,6 +1238,9 @@ __global__ void hrt_selftest_math_kernel(int fn, const float *in, float *out, ui
     case 1: y = hrt_cosf(x); break;
     case 2: y = hrt_expf(x); break;
     case 3: y = hrt_acosf(x); break;
+    case 5: { float c_; hrt_sincosf(x, &y, &c_); break; }
+    case 6: { float s_; hrt_sincosf(x, &s_, &y); break; }
+    case 7: y = hrt_cosf_nb(x); break;
     default: {   // src/compute_paths.c:281-283 with dot(n, d) = x
         float th = (float)acos((double)x);
         if (th > kPi * 0.5f) th = kPi - th;

@@ -204,7 +204,9 @@ int hrt_scene_import_sionna(const char *xml_path, Scene *out);
 /* Device self test: evaluates on the GPU, over n host floats, one of the float libm
  * restatements the shading code uses -- fn 0 sinf, 1 cosf, 2 expf, 3 acosf (csrc/hrt_libm.h)
  * -- or, fn 4, the incidence angle of src/compute_paths.c:281-283 for dot(n, d) = in[i]
- * ((float)acos((double)x) folded to [0, pi/2]).  Tests compare the result with the host libm. */
+ * ((float)acos((double)x) folded to [0, pi/2]); fn 5 / 6 the sine / cosine of the fused
+ * hrt_sincosf and fn 7 hrt_cosf_nb (the branch-free forms the shade kernel calls).  Tests compare
+ * the result with the host libm. */
 int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t n);
 
 /* Diagnostic counters of the packet-culling loop; all zero unless the library was built with

@@ -1,7 +1,7 @@
 /* libm_probe.c -- pins hermespy-rt_amd/csrc/hrt_libm.h against the HOST libm.
  *
  * TEST INFRASTRUCTURE (oracle/): compiles the product's device math header for the host and
- * compares hrt_sinf/hrt_cosf/hrt_expf/hrt_acosf with the libm this machine's reference build
+ * compares hrt_sinf/hrt_cosf/hrt_sincosf/hrt_cosf_nb/hrt_expf/hrt_acosf with the libm this machine's reference build
  * would call, bit for bit, over the domain the tracer can produce.
  *
  *   libm_probe            every 1009th float of each domain (about 2 s)
@@ -35,11 +35,14 @@ static unsigned long long sweep(const char *name, fn cand, fn ref, float lo, flo
                 ++bad;
             }
         }
-    printf("%-6s |x| in [%g, %g)  checked %llu  mismatches %llu", name, lo, hi, n, bad);
+    printf("%-9s |x| in [%g, %g)  checked %llu  mismatches %llu", name, lo, hi, n, bad);
     if (bad) printf("  first at %a", first);
     printf("\n");
     return bad;
 }
+
+static float sc_sin(float x) { float s, c; hrt_sincosf(x, &s, &c); return s; }
+static float sc_cos(float x) { float s, c; hrt_sincosf(x, &s, &c); return c; }
 
 int main(int argc, char **argv)
 {
@@ -47,6 +50,9 @@ int main(int argc, char **argv)
     unsigned long long bad = 0;
     bad += sweep("sinf", hrt_sinf, sinf, 0.f, 120.f, stride);
     bad += sweep("cosf", hrt_cosf, cosf, 0.f, 120.f, stride);
+    bad += sweep("sincosf.s", sc_sin, sinf, 0.f, 120.f, stride);
+    bad += sweep("sincosf.c", sc_cos, cosf, 0.f, 120.f, stride);
+    bad += sweep("cosf_nb", hrt_cosf_nb, cosf, 0.f, 120.f, stride);
     bad += sweep("expf", hrt_expf, expf, 0.f, 88.f, stride);
     bad += sweep("acosf", hrt_acosf, acosf, 0.f, 1.0000001f, stride);
     printf("%s\n", bad ? "MISMATCH" : "OK: device math header == host libm on every probed input");

@@ -36,6 +36,20 @@ DOMAINS = {
 }
 
 
+# the branch-free pair / cosine the shading kernel actually calls: (selftest code, host function)
+FUSED = {"sincosf.sin": (5, "sinf"), "sincosf.cos": (6, "cosf"), "cosf_nb": (7, "cosf")}
+
+
+@pytest.mark.parametrize("name", list(FUSED))
+def test_device_fused_sincos_bit_exact(product_lib, name):
+    code, host = FUSED[name]
+    x = _floats(0.0, 120.0, 131)
+    got = _device_eval(product_lib, code, x)
+    ref = oracle.host_libm(host, x)
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), "%s: %d of %d differ, e.g. x=%r" % (name, (~same).sum(), x.size, x[~same][:3])
+
+
 @pytest.mark.parametrize("name", list(DOMAINS))
 def test_device_libm_bit_exact(product_lib, name):
     lo, hi, stride = DOMAINS[name]
