@@ -16,7 +16,7 @@ The reference holds no golden values of its own (test/test.py asserts shapes onl
 ARE the golden vectors of this path.  Nothing of the reference's code is stored: only inputs
 (named configs of tests/configs.py) and output data.
 
-    python tests/golden/make_golden.py [--full]     # --full also regenerates full_size.json
+    python tests/golden/make_golden.py [--full [--only NAME]]   # --full also regenerates full_size.json
 """
 import ctypes
 import json
@@ -44,7 +44,8 @@ SMALL = {
     "coincident_3000": K.small(K.COINCIDENT, 3000),
 }
 
-FULL = {"C1": K.C1, "C2": K.C2, "C3": K.C3, "C4_1M": K.small(K.C4, 1000000)}
+FULL = {"C1": K.C1, "C2": K.C2, "C3": K.C3, "C4_1M": K.small(K.C4, 1000000),
+        "C5_1M": K.small(K.C5, 1000000)}   # 8 TX x 8 RX x 8 bounces: ~25 GB of dense arrays, ~3 min
 
 M64 = (1 << 64) - 1
 
@@ -107,15 +108,20 @@ def flat(res):
 
 def main():
     lib = load_ref()
-    for name, c in SMALL.items():
+    for name, c in ({} if "--only" in sys.argv else SMALL).items():
         r = abi.run_compute_paths(lib, *K.args(c))
         assert not abi.written(r["scat"]["directions_tx"]).any()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **flat(r))
         print("%-24s %8d bytes" % (name, os.path.getsize(path)))
     if "--full" in sys.argv:
-        summ = {}
+        # --only NAME regenerates one entry and keeps the others
+        only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+        path = os.path.join(HERE, "full_size.json")
+        summ = json.load(open(path)) if only and os.path.exists(path) else {}
         for name, c in FULL.items():
+            if only and name != only:
+                continue
             r = abi.run_compute_paths(lib, *K.args(c), with_rays=True)
             nb, npth = c["num_bounces"], c["num_paths"]
             ntx = len(c["tx_pos"])

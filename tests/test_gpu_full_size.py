@@ -16,7 +16,8 @@ from . import configs as K
 
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size.json")))
-CASES = {"C1": K.C1, "C2": K.C2, "C3": K.C3, "C4_1M": K.small(K.C4, 1000000)}
+CASES = {"C1": K.C1, "C2": K.C2, "C3": K.C3, "C4_1M": K.small(K.C4, 1000000),
+         "C5_1M": K.small(K.C5, 1000000)}
 
 
 def _lsr(x, n):
