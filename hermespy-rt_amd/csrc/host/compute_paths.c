@@ -88,6 +88,53 @@ typedef struct {
     int device;
 } work_t;
 
+/* ---- launch-table cache -------------------------------------------------------------------
+ * The launch directions depend on num_rays only, and the coherent launch order of an unbatched
+ * call on them only: callers that sample a channel again and again (moving endpoints, same ray
+ * count) would otherwise spend a third of every call recomputing 3*np double-precision libm
+ * results.  One entry (the last num_rays), owned by the library until hrt_cache_clear() or the
+ * next different num_rays; HRT_NO_CACHE=1 disables it; tables beyond 1 GiB are not kept. */
+static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct { uint64_t np; float *dirs; uint32_t *order; } g_cache;
+
+void hrt_cache_clear(void)
+{
+    pthread_mutex_lock(&g_cache_lock);
+    free(g_cache.dirs); free(g_cache.order);
+    g_cache.np = 0; g_cache.dirs = NULL; g_cache.order = NULL;
+    pthread_mutex_unlock(&g_cache_lock);
+}
+
+static int cache_enabled(uint64_t np) { return !env_int("HRT_NO_CACHE", 0) && np * 16 <= (1ull << 30); }
+
+/* copies of the cached tables for `np` into dirs / order (either may be NULL); 1 if served */
+static int cache_get(uint64_t np, float *dirs, uint32_t *order)
+{
+    int hit = 0;
+    pthread_mutex_lock(&g_cache_lock);
+    if (g_cache.np == np && g_cache.dirs && (!order || g_cache.order)) {
+        if (dirs) memcpy(dirs, g_cache.dirs, np * 12);
+        if (order) memcpy(order, g_cache.order, np * 4);
+        hit = 1;
+    }
+    pthread_mutex_unlock(&g_cache_lock);
+    return hit;
+}
+
+static void cache_put(uint64_t np, const float *dirs, const uint32_t *order)
+{
+    if (!cache_enabled(np)) return;
+    pthread_mutex_lock(&g_cache_lock);
+    if (g_cache.np != np) {
+        free(g_cache.dirs); free(g_cache.order);
+        g_cache.dirs = NULL; g_cache.order = NULL; g_cache.np = np;
+    }
+    if (dirs && !g_cache.dirs && (g_cache.dirs = (float *)malloc(np * 12))) memcpy(g_cache.dirs, dirs, np * 12);
+    if (order && !g_cache.order && (g_cache.order = (uint32_t *)malloc(np * 4))) memcpy(g_cache.order, order, np * 4);
+    if (!g_cache.dirs) { free(g_cache.order); g_cache.order = NULL; g_cache.np = 0; }
+    pthread_mutex_unlock(&g_cache_lock);
+}
+
 static void work_free(work_t *w)
 {
     if (w->d_dirs) hrt_device_free(w->device, w->d_dirs);
@@ -192,8 +239,11 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     hrt_shard whole = {np, 0, 1, 0, (uint32_t)nb};
     w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
     if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-    rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
-    if (rc) goto done;
+    if (!(cache_enabled(np) && cache_get(np, w.h_dirs, NULL))) {
+        rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
+        if (rc) goto done;
+        cache_put(np, w.h_dirs, NULL);
+    }
     st.t_launch_dirs_s = hrt_now_s() - t0;
 
     /* ---- dense pre-fills that do not depend on the trace ---- */
@@ -293,7 +343,10 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             src = w.dirs_batch;
         }
         t0 = hrt_now_s();
-        if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
+        if (!(G == 1 && cache_enabled(np) && cache_get(np, NULL, w.h_order))) {
+            if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
+            if (G == 1) cache_put(np, w.h_dirs, w.h_order);
+        }
         st.t_launch_dirs_s += hrt_now_s() - t0;   /* host-side launch preparation */
         t0 = hrt_now_s();
         if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;

@@ -551,6 +551,7 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT;
     const unsigned long long inval = HRT_BALLOT(!valid);
+    if (inval == ~0ull) return {who, best};   // a wave past the end of the live list
     {
         const Packet P = packet_bounds(B, d, valid, shadow, apex);
         HRT_STAT(kind, 0, 1);

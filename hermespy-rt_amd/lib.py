@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libhermespy_rt_amd.so")
 #: every symbol include/hermespy_rt.h and include/hrt_device.h declare
 EXPORTED = (
     "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_last_error",
-    "hrt_version", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
+    "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
     "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_layout_query", "hrt_trace",
@@ -83,6 +83,7 @@ def load():
     f32p = C.POINTER(C.c_float)
     L.hrt_last_error.restype = C.c_char_p
     L.hrt_version.restype = C.c_char_p
+    L.hrt_cache_clear.restype = None
     L.hrt_compute_paths_ex.restype = C.c_int
     L.hrt_compute_paths_ex.argtypes = [
         C.POINTER(abi.Scene), V3, V3, V3, V3, C.c_float, C.c_size_t, C.c_size_t, C.c_size_t,

@@ -129,6 +129,11 @@ const char *hrt_last_error(void);
 /* "hermespy-rt_amd <version> (gfx950)" */
 const char *hrt_version(void);
 
+/* compute_paths keeps the launch-direction table (and launch order) of the last num_rays between
+ * calls -- they depend on num_rays only; see csrc/host/compute_paths.c.  This frees it.
+ * Environment: HRT_NO_CACHE=1 disables the cache. */
+void hrt_cache_clear(void);
+
 #ifdef __cplusplus
 }
 #endif
