@@ -149,6 +149,15 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
                 cr[1] = sqrtf(e2.x * e2.x + e2.y * e2.y + e2.z * e2.z) * 1.000001f;
                 cr[2] = sqrtf(e3.x * e3.x + e3.y * e3.y + e3.z * e3.z) * 1.000001f;
                 cr[3] = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z) * 1.000001f;
+                /* triangle-only parts of the culling tolerances (hrt_kernels.hip packet_culls),
+                 * rounded up: E_d = 16 eps |e1||e2|, 4 eps a_N with a_N = 1.0001 |N| + E_d, and
+                 * c_w = 8 eps a_N + 2 E_d + 4e-6 |N| */
+                const double eps = 1.1920928955078125e-07, up = 1.000001;
+                const double Ed = 16.0 * eps * (double)cr[0] * (double)cr[1];
+                const double c2 = 4.0 * eps * (1.0001 * (double)cr[3] + Ed);
+                row[13] = (float)(Ed * up);
+                row[14] = (float)(c2 * up);
+                row[15] = (float)((2.0 * c2 + 2.0 * Ed + 4e-6 * (double)cr[3]) * up);
             }
             p->h_tri_mesh[j] = i;
             p->h_tri_face[j] = f;

@@ -414,29 +414,36 @@ __device__ __forceinline__ F3 fcross3(F3 a, F3 b)
             __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
 }
 
-// upper bounds of d.G (hp) and of -d.G (hm) over the cone (|d| = 1)
+// Bounds of d.G (hp) and of -d.G (hm) over the cone (|d| = 1), valid as UPPER bounds whenever they
+// are negative -- which is all the culling test asks of them (it compares them with a negative
+// threshold).  With beta the angle between the axis and G, the maximum of d.G over the cone is
+// g cos(beta - alpha) for beta > alpha and g otherwise; in the second case the first expression
+// is still positive (|beta - alpha| < 90 deg), so using it throughout never turns a "not culled"
+// into a "culled" and saves the select and the square root for g.  The 1e-4 relative slack (for
+// the roundoff of c1, s1 and the approximate v_sqrt) is taken on |c1| + s1 >= g.
 __device__ __forceinline__ void cone_bounds(const Packet &P, F3 G, float &hp, float &hm)
 {
     const float g2 = fdot3(G, G);
     const float c1 = fdot3(P.ax, G);                                       // g cos(beta)
     const float s1 = fast_sqrt(fmaxf(0.f, __builtin_fmaf(-c1, c1, g2)));   // g sin(beta)
-    const float g = fast_sqrt(g2);
-    const float gc = g * P.cosa, t1 = c1 * P.cosa, t2 = s1 * P.sina;
-    const float gs = __builtin_fmaf(1e-4f, g, g);
-    // axis within alpha of +-G: the maximum is g itself
-    hp = (c1 >= gc) ? gs : __builtin_fmaf(1e-4f, g, t2 + t1);
-    hm = (-c1 >= gc) ? gs : __builtin_fmaf(1e-4f, g, t2 - t1);
+    const float sl = fabsf(c1) + s1;
+    const float t1 = c1 * P.cosa, t2 = s1 * P.sina;
+    hp = __builtin_fmaf(1e-4f, sl, t2 + t1);
+    hm = __builtin_fmaf(1e-4f, sl, t2 - t1);
 }
 
-// true iff triangle row (q0,q1,q2) with lengths L = (|e1|, |e2|, |e2-e1|, |N|) is provably
-// rejected by the reference's test for every ray of the packet.  The acceptance conditions are
-// stated for sigma = sign(det_f), whatever it is: they are tested under BOTH hypotheses
-// sigma = +1 and sigma = -1 with the bounds of the whole cone, and the triangle is culled when
-// every hypothesis that is possible for some ray of the packet is rejected -- only one when
-// the cone does not straddle the triangle's plane, both otherwise (so triangles seen edge-on by
-// a wide packet are culled too, as long as they lie off to its side).
+// true iff triangle row (q0,q1,q2) with constants C = (-, E_d, 4 eps a_N, c_w) and lengths
+// L = (|e1|, |e2|, |e2-e1|, |N|) is provably rejected by the reference's test for every ray of the
+// packet.  The acceptance conditions are stated for sigma = sign(det_f), whatever it is: they are
+// tested under BOTH hypotheses sigma = +1 and sigma = -1 with the bounds of the whole cone, and
+// the triangle is culled when every hypothesis that is possible for some ray of the packet is
+// rejected -- only one when the cone does not straddle the triangle's plane, both otherwise (so
+// triangles seen edge-on by a wide packet are culled too, as long as they lie off to its side).
+// Tolerances (doubled): tol_u = 2 (2 eps a_N + E_u) = C.z + 2 E_u,  a_N = 1.0001 |N| + E_d,
+// tol_w = 2 (4 eps a_N + E_u + E_v + E_d) + 4e-6 |N| = C.w + 2 (E_u + E_v); the triangle-only
+// parts come from the table (problem.c), the parts proportional to S are formed here.
 __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 q1, float4 q2,
-                                             float4 L)
+                                             float4 C, float4 L)
 {
     constexpr float kE = 16.f * kEps;
     const F3 v1 = {q0.x, q0.y, q0.z};
@@ -446,26 +453,23 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const F3 sb = sub3(P.bc, v1);
     const float S = __builtin_fmaf(fast_sqrt(fdot3(sb, sb)), 1.0001f, P.br);
     const F3 sc = sub3(P.oc, v1);
-    const float Ed = kE * L.x * L.y;
     const float dn = fdot3(P.ax, nh);
     // all rays on one side of the plane's direction field: sigma = sign(det) = sign(-d.N) is known
     const bool one_sided =
-        L.w * __builtin_fmaf(fabsf(dn), P.cosa, -P.sina) > __builtin_fmaf(3.f, Ed, 1e-30f);
-    const float kS = kE * S;
-    const float Eu = kS * L.y, Ev = kS * L.x, Et = Eu * L.x;
-    const float aN = __builtin_fmaf(L.w, 1.0001f, Ed);
-    const float tol_u = 2.f * __builtin_fmaf(2.f * kEps, aN, Eu);
-    const float tol_v = 2.f * __builtin_fmaf(2.f * kEps, aN, Ev);
-    // N = e1 x e2 is taken as n * |N| (table values, ~2e-7 relative): covered by 4e-6 |N| in tol_w
-    const float tol_w = __builtin_fmaf(2.f, __builtin_fmaf(4.f * kEps, aN, Eu + Ev + Ed), 4e-6f * L.w);
+        L.w * __builtin_fmaf(fabsf(dn), P.cosa, -P.sina) > __builtin_fmaf(3.f, C.y, 1e-30f);
+    const float k2S = (2.f * kE) * S;                 // 2 E_u = k2S |e2|, 2 E_v = k2S |e1|
+    const float tol_u = __builtin_fmaf(k2S, L.y, C.z);
+    const float tol_v = __builtin_fmaf(k2S, L.x, C.z);
+    const float tol_w = __builtin_fmaf(k2S, L.x + L.y, C.w);
     // behind: sigma*Nt = sigma * (o - v1).N  with (o - v1).n in [h - br, h + br] (divided by |N|)
     const float h = fdot3(sb, nh);
-    const float thr = __builtin_fmaf(-1e-4f * L.w, fabsf(h) + P.br, -2.f * Et);
+    const float thr = __builtin_fmaf(-1e-4f * L.w, fabsf(h) + P.br, -(k2S * L.x) * L.y);   // -2 E_t
     bool rej_p = (P.br + h) * L.w < thr;
     bool rej_m = (P.br - h) * L.w < thr;
     // Nu = d.Gu, Nv = d.Gv, Nu + Nv - det = d.Gw (+- |edge| ro for the spread of the line points)
     const F3 Gu = fcross3(e2, sc);
     const F3 Gv = fcross3(sc, e1);
+    // N = e1 x e2 is taken as n * |N| (table values, ~2e-7 relative): covered by 4e-6 |N| in tol_w
     const F3 Gw = {__builtin_fmaf(nh.x, L.w, Gu.x + Gv.x), __builtin_fmaf(nh.y, L.w, Gu.y + Gv.y),
                    __builtin_fmaf(nh.z, L.w, Gu.z + Gv.z)};
     const float ro = P.ro * 1.0001f;
@@ -569,7 +573,8 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
             bool cand = false;
             if (jl < num_tri)
                 cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
-                                     tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 4]);
+                                     tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 3],
+                                     tri[HRT_ROW * jl + 4]);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
             HRT_STAT(kind, 2, __popcll(m));
 #ifdef HRT_KERNEL_STATS
