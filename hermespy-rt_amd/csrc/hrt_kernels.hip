@@ -451,7 +451,9 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
     const F3 e2 = {q1.z, q1.w, q2.x};
     const F3 nh = {q2.y, q2.z, q2.w};
     const F3 sb = sub3(P.bc, v1);
-    const float S = __builtin_fmaf(fast_sqrt(fdot3(sb, sb)), 1.0001f, P.br);
+    // S >= |o - v1| for every origin: the 1-norm of sb bounds its length (two adds instead of a
+    // dot product and a quarter-rate square root; S only scales tolerances of ~1e-6 relative)
+    const float S = (fabsf(sb.x) + fabsf(sb.y)) + (fabsf(sb.z) + P.br);
     const F3 sc = sub3(P.oc, v1);
     const float dn = fdot3(P.ax, nh);
     // all rays on one side of the plane's direction field: sigma = sign(det) = sign(-d.N) is known
