@@ -449,9 +449,13 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     if (rc) return rc;
     const uint64_t n0 = (uint64_t)p->num_tx * hrt_shard_num_local(s);
     if (n0 == 0) return hrt_fail(HRT_E_INVALID, "shard %u of %u is empty", s->rank, s->count);
-    if (n0 >= 0xffffff00ull)
-        return hrt_fail(HRT_E_CAPACITY, "num_tx * local rays = %llu does not fit 32-bit ray ids",
-                        (unsigned long long)n0);
+    /* the kernels address the field arrays of a block by 32-bit byte offsets from the block's
+     * buffer descriptor: HRT_HIT_FIELDS * cap * 4 < 2^32 */
+    if (n0 > 0xffffffffull / (4u * HRT_HIT_FIELDS) - 2u * HRT_BLOCK)
+        return hrt_fail(HRT_E_CAPACITY, "num_tx * local rays = %llu: more than %llu rays in one shard "
+                        "(32-bit offsets inside a block of field arrays); use more shards",
+                        (unsigned long long)n0,
+                        (unsigned long long)(0xffffffffull / (4u * HRT_HIT_FIELDS) - 2u * HRT_BLOCK));
     const uint64_t nb = s->num_bounces, cap = round_up(n0, HRT_BLOCK);
     memset(L, 0, sizeof *L);
     L->cap = cap;

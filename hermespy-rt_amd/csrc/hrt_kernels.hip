@@ -720,6 +720,52 @@ __device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s,
 __device__ __noinline__ float acos_f_ool(float x) { return hrt_acosf(x); }
 
 
+// Field arrays are addressed through BUFFER RESOURCES: one 128-bit descriptor (SGPRs) per block of
+// field arrays -- the hit list of a bounce, the records of a (bounce, rx), the results of a trace
+// kind --, the field's offset inside the block as the instruction's scalar offset, and the
+// entry's byte offset i*4 as ONE VGPR shared by all fields (`buffer_load_dword v, v_off, s[rsrc],
+// s_field offen`).  Plain `field[i]` indexing makes the compiler form a 64-bit address per field
+// in VGPRs (it cannot know that i*4 fits 32 bits): two VGPRs and a v_lshl_add_u64 per access,
+// ~120 VALU instructions and ~40 VGPRs in the shade kernel (102 -> 7x VGPRs).  One descriptor per
+// FIELD would do too, but the compiler hoists them all out of the loops and spills SGPRs.
+// The host guarantees HRT_HIT_FIELDS * cap * 4 < 2^32 (hrt_layout_query), so every scalar offset
+// fits; the descriptors' range is the whole 32-bit offset space (bounds are the host's business:
+// hrt_trace checks the workspace size).
+using Rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Rsrc make_rsrc(const uint8_t *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ float ldf(Rsrc r, uint32_t field_off, uint32_t byte_off)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)field_off, 0));
+}
+__device__ __forceinline__ uint32_t ldu(Rsrc r, uint32_t field_off, uint32_t byte_off)
+{
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)field_off, 0);
+}
+__device__ __forceinline__ void stf(Rsrc r, uint32_t field_off, uint32_t byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)field_off, 0);
+}
+__device__ __forceinline__ void stu(Rsrc r, uint32_t field_off, uint32_t byte_off, uint32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, (int)field_off, 0);
+}
+// blocks (include/hrt_device.h): hit list of bounce b; records of (bounce b, rx); results of kind k
+__device__ __forceinline__ Rsrc hit_blk(const hrt_kparams &P, uint32_t b)
+{
+    return make_rsrc(P.ws + P.off_hits + (uint64_t)b * P.hit_block_bytes);
+}
+__device__ __forceinline__ Rsrc rec_blk(const hrt_kparams &P, uint32_t b, uint32_t rx)
+{
+    return make_rsrc(P.ws + P.off_recs + (uint64_t)b * P.rec_block_bytes + (uint64_t)rx * 9u * P.cap * 4u);
+}
+__device__ __forceinline__ Rsrc res_blk(const hrt_kparams &P, uint32_t k)
+{
+    return make_rsrc(P.ws + P.off_res + (uint64_t)(2u * k) * P.cap * 4u);
+}
+
 // ---- workspace addressing (include/hrt_device.h) ----
 __device__ __forceinline__ float *hit_field(const hrt_kparams &P, uint32_t b, uint32_t f)
 {
@@ -806,6 +852,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     if (blockIdx.x >= n_units) return;
 
     const uint32_t T = P.num_tri;
+    const uint32_t cap4 = (uint32_t)P.cap * 4u;   // bytes per field array
     const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
     float4 *l_tri = lds;
     float4 *l_rx = lds + (TRI_IN_LDS ? HRT_ROW * T : 0u);
@@ -828,6 +875,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
         const uint32_t chunk = unit / kinds;
         const uint32_t k = k_lo + (unit - chunk * kinds);
         const uint32_t i = chunk * HRT_BLOCK + tid;
+        const uint32_t i4 = i * 4u;
         const bool valid = i < n_in;
         const bool shadow = k < P.num_rx;
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
@@ -837,11 +885,11 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
                 launch_ray(P, i, ray, o, d, tx);
             } else {
                 const uint32_t pb = b - 1;
-                o = {hit_field(P, pb, H_OX)[i], hit_field(P, pb, H_OY)[i],
-                     hit_field(P, pb, H_OZ)[i]};
+                o = {ldf(hit_blk(P, pb), H_OX * cap4, i4), ldf(hit_blk(P, pb), H_OY * cap4, i4),
+                     ldf(hit_blk(P, pb), H_OZ * cap4, i4)};
                 if (!shadow)
-                    d = {hit_field(P, pb, H_DX)[i], hit_field(P, pb, H_DY)[i],
-                         hit_field(P, pb, H_DZ)[i]};
+                    d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4),
+                         ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
             }
         }
         F3 apex = {0.f, 0.f, 0.f};
@@ -857,8 +905,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
         const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball, shadow, apex, l_mask,
                                            shadow ? 2 : (first ? 0 : 1));
         if (valid) {
-            res_tri(P, k)[i] = h.tri;
-            res_t(P, k)[i] = h.t;
+            stu(res_blk(P, k), 0u, i4, h.tri);
+            stf(res_blk(P, k), cap4, i4, h.t);
         }
         // the bounce itself: how many rays of this chunk survive.  The scan of these counts runs
         // BEFORE the shade kernel, which can then write every survivor straight to its final
@@ -900,6 +948,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;
 
     const float4 *tri = reinterpret_cast<const float4 *>(P.tri);   // per-lane rows: global/L2
+    const uint32_t cap4 = (uint32_t)P.cap * 4u;   // bytes per field array
     float4 *l_mat = lds;
     float4 *l_rx = l_mat + 4u * HRT_NUM_MATERIALS;
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(l_rx + P.num_rx);
@@ -915,6 +964,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     for (uint64_t base = (uint64_t)blockIdx.x * HRT_BLOCK; base < n_in;
          base += (uint64_t)gridDim.x * HRT_BLOCK) {
         const uint32_t i = (uint32_t)base + tid;
+        const uint32_t i4 = i * 4u;
         const bool valid = i < n_in;
 
         // ---- ray state ----
@@ -931,19 +981,19 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                 fs0 = dot3(tv, d) * P.dop_mult;
             } else {
                 const uint32_t pb = b - 1;
-                ray = __float_as_uint(hit_field(P, pb, H_RAY)[i]);
-                htri = __float_as_uint(hit_field(P, pb, H_TRI)[i]);
-                theta = hit_field(P, pb, H_THETA)[i];
-                fs0 = hit_field(P, pb, H_FS0)[i];
-                o = {hit_field(P, pb, H_OX)[i], hit_field(P, pb, H_OY)[i],
-                     hit_field(P, pb, H_OZ)[i]};
-                d = {hit_field(P, pb, H_DX)[i], hit_field(P, pb, H_DY)[i],
-                     hit_field(P, pb, H_DZ)[i]};
-                a0 = hit_field(P, pb, H_A0)[i];
-                a1 = hit_field(P, pb, H_A1)[i];
-                a2 = hit_field(P, pb, H_A2)[i];
-                a3 = hit_field(P, pb, H_A3)[i];
-                tau = hit_field(P, pb, H_TAU)[i];
+                ray = __float_as_uint(ldf(hit_blk(P, pb), H_RAY * cap4, i4));
+                htri = __float_as_uint(ldf(hit_blk(P, pb), H_TRI * cap4, i4));
+                theta = ldf(hit_blk(P, pb), H_THETA * cap4, i4);
+                fs0 = ldf(hit_blk(P, pb), H_FS0 * cap4, i4);
+                o = {ldf(hit_blk(P, pb), H_OX * cap4, i4), ldf(hit_blk(P, pb), H_OY * cap4, i4),
+                     ldf(hit_blk(P, pb), H_OZ * cap4, i4)};
+                d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4),
+                     ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
+                a0 = ldf(hit_blk(P, pb), H_A0 * cap4, i4);
+                a1 = ldf(hit_blk(P, pb), H_A1 * cap4, i4);
+                a2 = ldf(hit_blk(P, pb), H_A2 * cap4, i4);
+                a3 = ldf(hit_blk(P, pb), H_A3 * cap4, i4);
+                tau = ldf(hit_blk(P, pb), H_TAU * cap4, i4);
             }
         }
 
@@ -967,19 +1017,19 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                     const float4 rp = l_rx[rx];
                     float d2rx;
                     const F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
-                    uint32_t stri = res_tri(P, rx)[i];
-                    const float st = res_t(P, rx)[i];
+                    uint32_t stri = ldu(res_blk(P, rx), 0u, i4);
+                    const float st = ldf(res_blk(P, rx), cap4, i4);
                     if (stri != HRT_NO_HIT && stri >= P.num_tri) {   // cannot happen; never fault
                         atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
                         stri = HRT_NO_HIT;
                     }
                     if (stri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, stri), w);
                     if (stri != HRT_NO_HIT && st <= 1.f) {
-                        rec_field(P, pb, rx, R_A0)[i] = 0.f;
-                        rec_field(P, pb, rx, R_A1)[i] = 0.f;
-                        rec_field(P, pb, rx, R_A2)[i] = 0.f;
-                        rec_field(P, pb, rx, R_A3)[i] = 0.f;
-                        rec_field(P, pb, rx, R_TAU)[i] = 0.f;
+                        stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, 0.f);
+                        stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, 0.f);
+                        stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, 0.f);
+                        stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, 0.f);
+                        stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, 0.f);
                     } else {
                         unblocked = true;
                         const float th_s = acos_f_ool(dot3(w, n));
@@ -991,15 +1041,15 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                         float f2 = P.fsl_mult * d2rx;
                         f2 *= f2;
                         if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
-                        rec_field(P, pb, rx, R_A0)[i] = o0;
-                        rec_field(P, pb, rx, R_A1)[i] = o1;
-                        rec_field(P, pb, rx, R_A2)[i] = o2;
-                        rec_field(P, pb, rx, R_A3)[i] = o3;
-                        rec_field(P, pb, rx, R_TAU)[i] = tau + d2rx / kC;
-                        rec_field(P, pb, rx, R_DX)[i] = -w.x;
-                        rec_field(P, pb, rx, R_DY)[i] = -w.y;
-                        rec_field(P, pb, rx, R_DZ)[i] = -w.z;
-                        rec_field(P, pb, rx, R_DFS)[i] = dot3(sub3(w, d), mvel) * P.dop_mult;
+                        stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, o0);
+                        stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, o1);
+                        stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, o2);
+                        stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, o3);
+                        stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, tau + d2rx / kC);
+                        stf(rec_blk(P, pb, rx), R_DX * cap4, i4, -w.x);
+                        stf(rec_blk(P, pb, rx), R_DY * cap4, i4, -w.y);
+                        stf(rec_blk(P, pb, rx), R_DZ * cap4, i4, -w.z);
+                        stf(rec_blk(P, pb, rx), R_DFS * cap4, i4, dot3(sub3(w, d), mvel) * P.dop_mult);
                     }
                 }
                 const unsigned long long m = __ballot(unblocked);
@@ -1013,13 +1063,13 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             uint32_t ntri = 0;
             float nth = 0.f;
             if (valid) {
-                uint32_t ptri = res_tri(P, P.num_rx)[i];
+                uint32_t ptri = ldu(res_blk(P, P.num_rx), 0u, i4);
                 if (ptri != HRT_NO_HIT && ptri >= P.num_tri) {       // cannot happen; never fault
                     atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 2u);
                     ptri = HRT_NO_HIT;
                 }
                 if (ptri != HRT_NO_HIT) {
-                    const float pt = res_t(P, P.num_rx)[i];
+                    const float pt = ldf(res_blk(P, P.num_rx), cap4, i4);
                     hit = true;
                     ntri = ptri;
                     const F3 n = tri_normal(tri, ptri);
@@ -1057,23 +1107,23 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             __syncthreads();
             const uint32_t chunk = (uint32_t)(base / HRT_BLOCK);
             if (hit) {
-                const uint64_t k = (uint64_t)reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_off)[chunk] +
-                                   before + lane_prefix(m);
-                hit_field(P, b, H_RAY)[k] = __uint_as_float(ray);
-                hit_field(P, b, H_TRI)[k] = __uint_as_float(ntri);
-                hit_field(P, b, H_THETA)[k] = nth;
-                hit_field(P, b, H_FS0)[k] = fs0;
-                hit_field(P, b, H_OX)[k] = o.x;
-                hit_field(P, b, H_OY)[k] = o.y;
-                hit_field(P, b, H_OZ)[k] = o.z;
-                hit_field(P, b, H_DX)[k] = d.x;
-                hit_field(P, b, H_DY)[k] = d.y;
-                hit_field(P, b, H_DZ)[k] = d.z;
-                hit_field(P, b, H_A0)[k] = a0;
-                hit_field(P, b, H_A1)[k] = a1;
-                hit_field(P, b, H_A2)[k] = a2;
-                hit_field(P, b, H_A3)[k] = a3;
-                hit_field(P, b, H_TAU)[k] = tau;
+                const uint32_t k4 = (reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_off)[chunk] +
+                                     before + lane_prefix(m)) * 4u;
+                stf(hit_blk(P, b), H_RAY * cap4, k4, __uint_as_float(ray));
+                stf(hit_blk(P, b), H_TRI * cap4, k4, __uint_as_float(ntri));
+                stf(hit_blk(P, b), H_THETA * cap4, k4, nth);
+                stf(hit_blk(P, b), H_FS0 * cap4, k4, fs0);
+                stf(hit_blk(P, b), H_OX * cap4, k4, o.x);
+                stf(hit_blk(P, b), H_OY * cap4, k4, o.y);
+                stf(hit_blk(P, b), H_OZ * cap4, k4, o.z);
+                stf(hit_blk(P, b), H_DX * cap4, k4, d.x);
+                stf(hit_blk(P, b), H_DY * cap4, k4, d.y);
+                stf(hit_blk(P, b), H_DZ * cap4, k4, d.z);
+                stf(hit_blk(P, b), H_A0 * cap4, k4, a0);
+                stf(hit_blk(P, b), H_A1 * cap4, k4, a1);
+                stf(hit_blk(P, b), H_A2 * cap4, k4, a2);
+                stf(hit_blk(P, b), H_A3 * cap4, k4, a3);
+                stf(hit_blk(P, b), H_TAU * cap4, k4, tau);
             }
         }
     }

@@ -121,7 +121,7 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
 #define HRT_E_INVALID (-1)   /* bad argument (zero count, material_index > 16, ...) */
 #define HRT_E_NOMEM (-2)     /* host allocation failed */
 #define HRT_E_HIP (-3)       /* HIP runtime error; text via hrt_last_error() */
-#define HRT_E_CAPACITY (-4)  /* problem does not fit the device / 32-bit ray ids */
+#define HRT_E_CAPACITY (-4)  /* problem does not fit the device / > 71.5 M rays in one shard */
 
 /* Human-readable description of the last error on this thread ("" if none). */
 const char *hrt_last_error(void);
