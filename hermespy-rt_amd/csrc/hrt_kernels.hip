@@ -631,19 +631,6 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F
     }
 }
 
-template <typename TriPtr>
-__device__ __forceinline__ F3 tri_normal(TriPtr tri, uint32_t j)
-{
-    const float4 q2 = tri[HRT_ROW * j + 2];
-    return {q2.y, q2.z, q2.w};
-}
-
-template <typename TriPtr>
-__device__ __forceinline__ uint32_t tri_mesh(TriPtr tri, uint32_t j)
-{
-    return __float_as_uint(tri[HRT_ROW * j + 3].x);
-}
-
 // acos in double of the float dot product, stored to float, folded to [0, pi/2] with the
 // float pi (src/compute_paths.c:281-283).
 __device__ __noinline__ float incidence_angle(F3 n, F3 d)
@@ -751,6 +738,18 @@ __device__ __forceinline__ void stf(Rsrc r, uint32_t field_off, uint32_t byte_of
 __device__ __forceinline__ void stu(Rsrc r, uint32_t field_off, uint32_t byte_off, uint32_t v)
 {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, (int)field_off, 0);
+}
+// per-lane gathers from the triangle / mesh tables (shade kernel): row j, byte `at` inside the row
+__device__ __forceinline__ F3 gather3(Rsrc r, uint32_t row_bytes, uint32_t j, uint32_t at)
+{
+    const auto v = __builtin_amdgcn_raw_buffer_load_b96(r, (int)(j * row_bytes + at), 0, 0);
+    return {__uint_as_float((uint32_t)v[0]), __uint_as_float((uint32_t)v[1]), __uint_as_float((uint32_t)v[2])};
+}
+__device__ __forceinline__ float4 gather4(Rsrc r, uint32_t row_bytes, uint32_t j, uint32_t at)
+{
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(j * row_bytes + at), 0, 0);
+    return make_float4(__uint_as_float((uint32_t)v[0]), __uint_as_float((uint32_t)v[1]),
+                       __uint_as_float((uint32_t)v[2]), __uint_as_float((uint32_t)v[3]));
 }
 // blocks (include/hrt_device.h): hit list of bounce b; records of (bounce b, rx); results of kind k
 __device__ __forceinline__ Rsrc hit_blk(const hrt_kparams &P, uint32_t b)
@@ -947,7 +946,9 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     const uint32_t n_in = first ? P.n0 : counts[b];
     if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;
 
-    const float4 *tri = reinterpret_cast<const float4 *>(P.tri);   // per-lane rows: global/L2
+    // per-lane rows of the triangle and mesh tables: gathered from global memory (L2)
+    const Rsrc tri_r = make_rsrc(reinterpret_cast<const uint8_t *>(P.tri));
+    const Rsrc mesh_r = make_rsrc(reinterpret_cast<const uint8_t *>(P.mesh));
     const uint32_t cap4 = (uint32_t)P.cap * 4u;   // bytes per field array
     float4 *l_mat = lds;
     float4 *l_rx = l_mat + 4u * HRT_NUM_MATERIALS;
@@ -1003,9 +1004,9 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
             float mat_s = 0.f, mat_alpha = 1.f;
             if (valid) {
-                n = tri_normal(tri, htri);
-                const uint32_t mesh = tri_mesh(tri, htri);
-                const float4 mm = reinterpret_cast<const float4 *>(P.mesh)[mesh];
+                n = gather3(tri_r, HRT_TRI_FLOATS * 4u, htri, 36u);
+                const uint32_t mesh = ldu(tri_r, 0u, htri * (HRT_TRI_FLOATS * 4u) + 48u);
+                const float4 mm = gather4(mesh_r, HRT_MESH_FLOATS * 4u, mesh, 0u);
                 mvel = {mm.x, mm.y, mm.z};
                 const float4 m3 = l_mat[4u * __float_as_uint(mm.w) + 3u];
                 mat_s = m3.x;
@@ -1023,7 +1024,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                         atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
                         stri = HRT_NO_HIT;
                     }
-                    if (stri != HRT_NO_HIT) theta = incidence_angle(tri_normal(tri, stri), w);
+                    if (stri != HRT_NO_HIT)
+                        theta = incidence_angle(gather3(tri_r, HRT_TRI_FLOATS * 4u, stri, 36u), w);
                     if (stri != HRT_NO_HIT && st <= 1.f) {
                         stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, 0.f);
                         stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, 0.f);
@@ -1072,11 +1074,11 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                     const float pt = ldf(res_blk(P, P.num_rx), cap4, i4);
                     hit = true;
                     ntri = ptri;
-                    const F3 n = tri_normal(tri, ptri);
+                    const F3 n = gather3(tri_r, HRT_TRI_FLOATS * 4u, ptri, 36u);
                     nth = incidence_angle(n, d);
-                    const uint32_t mesh = tri_mesh(tri, ptri);
+                    const uint32_t mesh = ldu(tri_r, 0u, ptri * (HRT_TRI_FLOATS * 4u) + 48u);
                     const uint32_t mat =
-                        __float_as_uint(reinterpret_cast<const float4 *>(P.mesh)[mesh].w);
+                        ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
                     float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
                     float fsl = P.fsl_mult * pt;
                     fsl *= fsl;
