@@ -143,6 +143,9 @@ typedef struct {
     uint64_t off_res;
 } hrt_layout;
 
+/* HRT_E_CAPACITY when num_tx * (local rays) exceeds 2^32 / (HRT_HIT_FIELDS * 4) - 512
+ * (~71.5 M): the kernels address the field arrays of a block by 32-bit offsets from the block's
+ * buffer descriptor.  Use more shards (the drop-in compute_paths does so by itself). */
 int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
 
 /* Per-launch device times of one hrt_trace call, filled only when requested. */
