@@ -99,3 +99,27 @@ def test_shards_union_equals_unsharded(world, chunk):
         else:
             assert_bit_equal(merged[k], dfull[k], k)
     full.close()
+
+
+def test_rays_per_shard_limit():
+    """A shard may hold at most 2^32 / (HRT_HIT_FIELDS * 4) - 512 rays (32-bit offsets inside a
+    block of field arrays): hrt_layout_query refuses more with HRT_E_CAPACITY, and the same
+    total split over two shards is accepted."""
+    import ctypes as C
+    from hermespy_rt_amd import lib as _lib
+    from hermespy_rt_amd.device import Tracer
+    c = K.small(K.C1, 1000)
+    tr = Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"], c["f_ghz"],
+                c["num_paths"], c["num_bounces"])
+    L = _lib.load()
+    lay = _lib.Layout()
+    limit = (1 << 32) // (15 * 4) - 512
+    ok = _lib.Shard(limit, 0, 1, 0, 1)
+    assert L.hrt_layout_query(tr.problem, C.byref(ok), C.byref(lay)) == 0
+    assert 15 * lay.cap * 4 < (1 << 32)
+    too_big = _lib.Shard(limit + 4096, 0, 1, 0, 1)
+    assert L.hrt_layout_query(tr.problem, C.byref(too_big), C.byref(lay)) == -4      # HRT_E_CAPACITY
+    assert b"use more shards" in L.hrt_last_error()
+    halves = _lib.Shard(limit + 4096, 1, 2, 0, 1)
+    assert L.hrt_layout_query(tr.problem, C.byref(halves), C.byref(lay)) == 0
+    tr.close()
