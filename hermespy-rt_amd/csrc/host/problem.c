@@ -461,12 +461,15 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     L->cap = cap;
     uint64_t off = 0;
     L->off_counts = off; off += round_up((nb + 2) * 4, 256);
+    /* survivor counts per super-chunk (HRT_SUPER_CHUNKS chunks of 256 entries) and bounce: directly behind
+     * the counts, zeroed with them at the start of every trace */
+    L->num_super = cap / HRT_BLOCK / HRT_SUPER_CHUNKS + 1;
+    L->off_super_cnt = off; off += round_up(nb * L->num_super * 4, 256);
     L->off_los = off;    off += round_up((uint64_t)p->num_rx * p->num_tx * HRT_LOS_FLOATS * 4, 256);
     L->off_hits = off;   L->hit_block_bytes = (uint64_t)HRT_HIT_FIELDS * cap * 4; off += nb * L->hit_block_bytes;
     L->off_recs = off;   L->rec_block_bytes = (uint64_t)p->num_rx * HRT_REC_FIELDS * cap * 4; off += nb * L->rec_block_bytes;
     L->off_masks = off;  off += round_up(nb * p->num_rx * (cap / 64) * 8, 256);
     L->off_chunk_cnt = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
-    L->off_chunk_off = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
     L->off_res = off;    off += ((uint64_t)p->num_rx + 1) * 2 * cap * 4;
     L->total_bytes = off;
     return HRT_OK;
@@ -514,8 +517,8 @@ int hrt_timer_read(hrt_timer *t, hrt_kernel_times *times)
     STEP(hrt_hip_event_elapsed_ms(t->ev[0], t->ev[1], &times->los_ms));
     for (uint32_t b = 0; b <= nb && !hip; ++b) {
         STEP(hrt_hip_event_elapsed_ms(t->ev[2 + 4 * b], t->ev[3 + 4 * b], &times->trace_ms[b]));
-        STEP(hrt_hip_event_elapsed_ms(t->ev[3 + 4 * b], t->ev[4 + 4 * b], &times->compact_ms[b]));
-        STEP(hrt_hip_event_elapsed_ms(t->ev[4 + 4 * b], t->ev[5 + 4 * b], &times->shade_ms[b]));
+        times->compact_ms[b] = 0.f;   /* nothing runs between the two kernels any more */
+        STEP(hrt_hip_event_elapsed_ms(t->ev[3 + 4 * b], t->ev[5 + 4 * b], &times->shade_ms[b]));
     }
 #undef STEP
     times->num_bounce_launches = nb + 1;
@@ -581,7 +584,8 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.off_counts = L.off_counts; K.off_los = L.off_los; K.off_hits = L.off_hits;
     K.hit_block_bytes = L.hit_block_bytes; K.off_recs = L.off_recs;
     K.rec_block_bytes = L.rec_block_bytes; K.off_masks = L.off_masks;
-    K.off_chunk_cnt = L.off_chunk_cnt; K.off_chunk_off = L.off_chunk_off;
+    K.off_chunk_cnt = L.off_chunk_cnt; K.off_super_cnt = L.off_super_cnt;
+    K.num_super = (uint32_t)L.num_super;
     K.off_res = L.off_res;
 
     HRT_HIP(hrt_hip_set_device(p->device), "hipSetDevice");
@@ -593,7 +597,9 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
         return hrt_fail(HRT_E_INVALID, "timer was created for %u bounces, trace has %u", timer->num_bounces, nb);
     int hip = 0;
 #define STEP(call) do { if (!hip) hip = (call); } while (0)
-    STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0, (nb + 2) * 4, stream));
+    /* counts, device error flag, and the super-chunk counts right behind them */
+    STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0,
+                              L.off_super_cnt - L.off_counts + (uint64_t)nb * L.num_super * 4, stream));
     if (ev) STEP(hrt_hip_event_record(ev[0], stream));
     STEP(hrt_hip_launch_los(&K, stream));
     if (ev) STEP(hrt_hip_event_record(ev[1], stream));
@@ -601,8 +607,6 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
         if (ev) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
         STEP(hrt_hip_launch_trace(&K, b, stream));
         if (ev) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
-        if (b < nb) STEP(hrt_hip_launch_scan(&K, b, stream));
-        if (ev) STEP(hrt_hip_event_record(ev[4 + 4 * b], stream));
         STEP(hrt_hip_launch_shade(&K, b, stream));
         if (ev) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
     }

@@ -311,6 +311,27 @@ __device__ __forceinline__ F3 wave_sum3(F3 v)
     return {lane63(v.x), lane63(v.y), lane63(v.z)};
 }
 
+// sum of a u32 over the wave, in every lane's SGPR-uniform result
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    asm volatile(
+        "s_nop 4\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ float wave_min_f(float v)
 {
     asm volatile(
@@ -907,16 +928,21 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
             stu(res_blk(P, k), 0u, i4, h.tri);
             stf(res_blk(P, k), cap4, i4, h.t);
         }
-        // the bounce itself: how many rays of this chunk survive.  The scan of these counts runs
-        // BEFORE the shade kernel, which can then write every survivor straight to its final
-        // place in the next live list (stable compaction without a staging copy).
+        // the bounce itself: how many rays of this chunk survive.  With the counts of all chunks
+        // known BEFORE the shade kernel runs, that kernel can write every survivor straight to
+        // its final place in the next live list (stable compaction without a staging copy).
         if (!shadow) {
             const unsigned long long hm = __ballot(valid && h.tri != HRT_NO_HIT);
             if (lane == 0) l_wcnt[tid >> 6] = (uint32_t)__popcll(hm);
             __syncthreads();
-            if (tid == 0)
-                reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] =
-                    l_wcnt[0] + l_wcnt[1] + l_wcnt[2] + l_wcnt[3];
+            if (tid == 0) {
+                const uint32_t c = l_wcnt[0] + l_wcnt[1] + l_wcnt[2] + l_wcnt[3];
+                reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] = c;
+                // ... and the sum over every HRT_SUPER_CHUNKS chunks ("super-chunk"): two short sums in the
+                // shade kernel then replace a scan pass over all chunks
+                atomicAdd(reinterpret_cast<uint32_t *>(P.ws + P.off_super_cnt) +
+                              (uint64_t)b * P.num_super + (chunk >> HRT_SUPER_SHIFT), c);
+            }
             __syncthreads();
         }
     }
@@ -930,7 +956,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
 //   (b < nb) the bounce itself: incidence angle, Fresnel, FSL, delay, reflect (:611-659), and
 //            step 1 of the stable compaction (survivors of the 256-entry chunk to the front
 //            of the chunk's slice of the staging block, count to chunk_cnt).
-// LDS: [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts]
+// LDS: [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts][4 u32 wave sums]
 // ===================================================================================
 #ifndef HRT_SHADE_WAVES
 #define HRT_SHADE_WAVES 5   /* 96 VGPRs (8 dwords spilled): 5 waves/SIMD instead of 4, shade -5 % */
@@ -1096,21 +1122,43 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                 }
             }
             // STABLE compaction: survivors of this 256-entry chunk, in input order, go to
-            // chunk_off[chunk] + rank of the next live list.  chunk_off is the exclusive scan
-            // (hrt_scan_kernel, run between the trace and the shade kernel) of the per-chunk
-            // survivor counts the trace kernel produced -- so the next list keeps the (coherent)
-            // order of this one, without a staging copy.
+            // offset(chunk) + rank of the next live list, offset(chunk) = survivors of all earlier
+            // chunks = sum of the earlier super-chunks' counts + sum of the earlier chunks' counts
+            // of this super-chunk (both written by the trace kernel of this launch): a few loads
+            // per thread and one workgroup reduction, no scan pass -- and the next list keeps the
+            // (coherent) order of this one, without a staging copy.
+            const uint32_t chunk = (uint32_t)(base / HRT_BLOCK);
+            const uint32_t sup = chunk >> HRT_SUPER_SHIFT;
+            uint32_t part = 0;
+            {
+                const uint32_t *scnt = reinterpret_cast<const uint32_t *>(P.ws + P.off_super_cnt) +
+                                       (uint64_t)b * P.num_super;
+                const uint32_t *ccnt = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_cnt);
+                // chunk 0 also owes the total (all super-chunks): counts[b+1]
+                const uint32_t n_sup =
+                    (chunk == 0) ? ((n_in + HRT_BLOCK - 1) / HRT_BLOCK + HRT_SUPER_CHUNKS - 1u) >> HRT_SUPER_SHIFT : sup;
+                for (uint32_t q = tid; q < n_sup; q += HRT_BLOCK) part += scnt[q];
+                const uint32_t c = (sup << HRT_SUPER_SHIFT) + tid;
+                if (chunk != 0 && tid < HRT_SUPER_CHUNKS && c < chunk) part += ccnt[c];
+            }
+            part = wave_sum_u32(part);
             const unsigned long long m = __ballot(hit);
-            if (lane == 0) l_wcnt[wave] = (uint32_t)__popcll(m);
+            if (lane == 0) {
+                l_wcnt[wave] = (uint32_t)__popcll(m);
+                l_wcnt[4 + wave] = part;
+            }
             __syncthreads();
             uint32_t before = 0;
 #pragma unroll
             for (uint32_t w = 0; w < HRT_BLOCK / 64u; ++w) before += (w < wave) ? l_wcnt[w] : 0u;
+            uint32_t chunk_off = l_wcnt[4] + l_wcnt[5] + l_wcnt[6] + l_wcnt[7];
             __syncthreads();
-            const uint32_t chunk = (uint32_t)(base / HRT_BLOCK);
+            if (chunk == 0) {
+                if (tid == 0) const_cast<uint32_t *>(counts)[b + 1] = chunk_off;
+                chunk_off = 0;
+            }
             if (hit) {
-                const uint32_t k4 = (reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_off)[chunk] +
-                                     before + lane_prefix(m)) * 4u;
+                const uint32_t k4 = (chunk_off + before + lane_prefix(m)) * 4u;
                 stf(hit_blk(P, b), H_RAY * cap4, k4, __uint_as_float(ray));
                 stf(hit_blk(P, b), H_TRI * cap4, k4, __uint_as_float(ntri));
                 stf(hit_blk(P, b), H_THETA * cap4, k4, nth);
@@ -1129,36 +1177,6 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             }
         }
     }
-}
-
-// STABLE compaction: exclusive scan of the per-chunk survivor counts of bounce b (written by the
-// trace kernel; one workgroup; at most cap/256 chunks) -> chunk_off[], total -> counts[b+1].
-__global__ __launch_bounds__(1024) void hrt_scan_kernel(const hrt_kparams P, const uint32_t b)
-{
-    __shared__ uint32_t part[1024];
-    uint32_t *counts = reinterpret_cast<uint32_t *>(P.ws + P.off_counts);
-    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(P.ws + P.off_chunk_cnt);
-    uint32_t *off = reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_off);
-    const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
-    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
-    const uint32_t per = (n_chunks + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_chunks);
-    uint32_t sum = 0;
-    for (uint32_t c = lo; c < hi; ++c) sum += cnt[c];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t s = 1; s < 1024u; s <<= 1) {   // Hillis-Steele inclusive scan
-        const uint32_t v = (threadIdx.x >= s) ? part[threadIdx.x - s] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t c = lo; c < hi; ++c) {
-        off[c] = run;
-        run += cnt[c];
-    }
-    if (threadIdx.x == 1023u) counts[b + 1] = part[1023];
 }
 
 // LoS pass (src/compute_paths.c:515-577): one WAVE per (rx, tx) pair, the lanes share the
@@ -1416,17 +1434,9 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
     static const uint64_t max_grid = env_u64("HRT_SHADE_GRID", HRT_SHADE_GRID);
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
-    const size_t lds = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)P->num_rx * 16u + 16u;
+    const size_t lds = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)P->num_rx * 16u + 32u;
     hipLaunchKernelGGL(hrt_shade_kernel, dim3((uint32_t)blocks), dim3(HRT_BLOCK), lds,
                        (hipStream_t)stream, *P, bounce);
-    return (int)hipGetLastError();
-}
-
-// stable compaction of the survivors of `bounce`: scan of the chunk counts (between the trace
-// and the shade kernel)
-int hrt_hip_launch_scan(const hrt_kparams *P, uint32_t bounce, void *stream)
-{
-    hipLaunchKernelGGL(hrt_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *P, bounce);
     return (int)hipGetLastError();
 }
 

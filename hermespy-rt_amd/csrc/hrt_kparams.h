@@ -15,6 +15,13 @@ extern "C" {
 #define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */
 #define HRT_MESH_FLOATS 4  /* velocity(3), material_index(u32) */
 #define HRT_BLOCK 256
+/* a super-chunk = 2^HRT_SUPER_SHIFT chunks: the trace kernel adds every chunk's survivor count to
+ * its super-chunk's (one atomic per chunk: fewer chunks per super-chunk = less contention), the
+ * shade kernel sums the earlier super-chunks and the earlier chunks of its own */
+#ifndef HRT_SUPER_SHIFT
+#define HRT_SUPER_SHIFT 5
+#endif
+#define HRT_SUPER_CHUNKS (1u << HRT_SUPER_SHIFT)
 #define HRT_TRACE_GRID 8192   /* persistent workgroups of the trace kernel */
 #define HRT_SHADE_GRID 16384
 /* triangle tables up to this many bytes are staged in LDS (160 KiB per CU on gfx950, minus
@@ -44,7 +51,8 @@ typedef struct {
     uint8_t *ws;
     uint64_t cap;
     uint64_t off_counts, off_los, off_hits, hit_block_bytes, off_recs, rec_block_bytes,
-        off_masks, off_chunk_cnt, off_chunk_off, off_res;
+        off_masks, off_chunk_cnt, off_super_cnt, off_res;
+    uint32_t num_super;   /* super-chunks per bounce */
 } hrt_kparams;
 
 /* ---- the shim (hrt_kernels.hip).  All return 0 or a positive hipError_t. ---- */
@@ -62,7 +70,6 @@ int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
-int hrt_hip_launch_scan(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream);

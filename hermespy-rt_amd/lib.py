@@ -37,7 +37,8 @@ class Shard(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "total_bytes", "cap", "off_counts", "off_los", "off_hits", "hit_block_bytes",
-        "off_recs", "rec_block_bytes", "off_masks", "off_chunk_cnt", "off_chunk_off", "off_res")]
+        "off_recs", "rec_block_bytes", "off_masks", "off_chunk_cnt", "off_super_cnt", "off_res",
+        "num_super")]
 
 
 class KernelTimes(C.Structure):

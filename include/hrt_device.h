@@ -136,11 +136,13 @@ typedef struct {
                                                        + (rx*HRT_REC_FIELDS + f)*cap*4 */
     uint64_t rec_block_bytes;
     uint64_t off_masks;         /* u64 words of (b, rx) at off_masks + (b*num_rx + rx)*(cap/64)*8 */
-    /* scratch of the stable compaction (per-chunk survivor counts and their exclusive scan) */
-    uint64_t off_chunk_cnt, off_chunk_off;
+    /* scratch of the stable compaction: survivor counts per 256-entry chunk, and per bounce the
+     * sums over every 32 chunks (u32 [num_bounces][num_super]) */
+    uint64_t off_chunk_cnt, off_super_cnt;
     /* trace results of one launch: for trace kind k (0..num_rx-1 shadow to rx k, num_rx the
      * bounce itself) u32 triangle[cap] then f32 distance[cap] at off_res + (2k, 2k+1)*cap*4 */
     uint64_t off_res;
+    uint64_t num_super;
 } hrt_layout;
 
 /* HRT_E_CAPACITY when num_tx * (local rays) exceeds 2^32 / (HRT_HIT_FIELDS * 4) - 512
@@ -153,7 +155,8 @@ typedef struct {
     float los_ms;
     float trace_ms[33];         /* trace kernel (all intersection work) of launch b = 0..num_bounces */
     float shade_ms[33];         /* shade kernel (records, Fresnel, reflect) of launch b */
-    float compact_ms[33];       /* scan kernel of the stable compaction of launch b (0 for the last) */
+    float compact_ms[33];       /* between the trace and the shade kernel of launch b (nothing runs
+                                 * there any more: ~0) */
     uint32_t num_bounce_launches;
 } hrt_kernel_times;
 
