@@ -364,6 +364,26 @@ struct Packet {
     bool usable;
 };
 
+// The culling test needs conservative bounds, not exact values: it uses the single-instruction
+// approximate v_sqrt_f32 / v_rsq_f32 (1 ulp) instead of the IEEE-correct expansions (~15
+// instructions each); their error is far inside the 1e-4 relative slack added below.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// The culling test is free to round differently from the reference (it only needs conservative
+// bounds; everything that survives runs the reference's exact sequence), so unlike the rest of
+// this file it uses fused multiply-adds: a dot product is 3 instructions instead of 5, a cross
+// product 6 instead of 9 -- the kernel is VALU-issue-bound, so that is time.
+__device__ __forceinline__ float fdot3(F3 a, F3 b)
+{
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
+__device__ __forceinline__ F3 fcross3(F3 a, F3 b)
+{
+    return {__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+            __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
+}
+
 // must be called by ALL lanes of the wave (valid = lane carries a real ray)
 __device__ __forceinline__ Ball origin_ball(F3 o, bool valid)
 {
@@ -376,7 +396,7 @@ __device__ __forceinline__ Ball origin_ball(F3 o, bool valid)
     B.c = {0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz)};
     const F3 ext = {hix - lox, hiy - loy, hiz - loz};
     // half diagonal of the bounding box, rounded up
-    B.r = 0.5f * sqrtf(dot3(ext, ext)) * 1.00001f +
+    B.r = 0.5f * fast_sqrt(fdot3(ext, ext)) * 1.0001f +
           1e-6f * (fabsf(B.c.x) + fabsf(B.c.y) + fabsf(B.c.z));
     B.ok = lox <= hix;
     return B;
@@ -396,43 +416,25 @@ __device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid,
     if (shadow) {
         P.oc = apex;
         const F3 v = sub3(apex, B.c);
-        const float lmax = sqrtf(dot3(v, v)) * 1.00001f + B.r;
+        const float lmax = fast_sqrt(fdot3(v, v)) * 1.0001f + B.r;
         P.ro = 8.f * (0.5f * kEps) * lmax + 1e-7f;
     } else {
         P.oc = B.c;
         P.ro = B.r;
     }
     const F3 sd = wave_sum3({valid ? d.x : 0.f, valid ? d.y : 0.f, valid ? d.z : 0.f});
-    const float n2 = dot3(sd, sd);
-    const float inv = 1.f / sqrtf(fmaxf(n2, 1e-30f));
+    // (bounds, not reference arithmetic: approximate rsq/sqrt and FMAs, like the culling test)
+    const float n2 = fdot3(sd, sd);
+    const float inv = fast_rsq(fmaxf(n2, 1e-30f));
     P.ax = {sd.x * inv, sd.y * inv, sd.z * inv};
-    float c = wave_min_f(valid ? dot3(d, P.ax) : 1.f);
-    c = c * (1.f - 1e-5f) - 1e-6f;   // |d| is 1 within ~1e-6: widen the cone instead
+    float c = wave_min_f(valid ? fdot3(d, P.ax) : 1.f);
+    // |d| and |ax| are 1 within ~1e-6: widen the cone instead
+    c = c * (1.f - 1e-5f) - 2e-6f;
     P.cosa = c;
-    P.sina = sqrtf(fmaxf(0.f, 1.f - c * c));
+    P.sina = fast_sqrt(fmaxf(0.f, __builtin_fmaf(-c, c, 1.f))) * 1.00001f + 1e-7f;
     // wide packets (half-angle > ~60 deg) or degenerate axis: culling cannot pay
     P.usable = (n2 > 1e-12f) && (c > 0.5f) && B.ok;
     return P;
-}
-
-// The culling test needs conservative bounds, not exact values: it uses the single-instruction
-// approximate v_sqrt_f32 / v_rsq_f32 (1 ulp) instead of the IEEE-correct expansions (~15
-// instructions each); their error is far inside the 1e-4 relative slack added below.
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-
-// The culling test is free to round differently from the reference (it only needs conservative
-// bounds; everything that survives runs the reference's exact sequence), so unlike the rest of
-// this file it uses fused multiply-adds: a dot product is 3 instructions instead of 5, a cross
-// product 6 instead of 9 -- the kernel is VALU-issue-bound, so that is time.
-__device__ __forceinline__ float fdot3(F3 a, F3 b)
-{
-    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
-}
-__device__ __forceinline__ F3 fcross3(F3 a, F3 b)
-{
-    return {__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
-            __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
 }
 
 // Bounds of d.G (hp) and of -d.G (hm) over the cone (|d| = 1), valid as UPPER bounds whenever they
