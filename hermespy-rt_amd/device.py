@@ -241,6 +241,78 @@ class Tracer:
         return dict(live=[int(st.live[i]) for i in range(self.nb + 1)], records=int(st.records),
                     tests=int(st.tests))
 
+    # ------------------------------------------------------------------ path list (COO)
+    def paths(self, nonzero_only=True, with_geometry=False):
+        """The resolved scatter paths of the last trace as ONE list (device tensors), the form a
+        channel model consumes -- instead of the reference's dense [rx][tx][bounce][path] arrays
+        of which > 95 % are never written:
+
+            rx, tx, bounce, path   int64 [n]   indices of the dense slot the record belongs to
+                                               (path = GLOBAL path index, also on a shard)
+            a_te, a_tm             complex64   gains (a blocked record has zeros)
+            tau                    float32     delay; direction_rx float32 [n, 3]
+            freq_shift             float32     launch Doppler term of the ray minus the record's
+                                               (= the dense array's value for one TX; the
+                                               reference's dense fill is undefined for more, Q9)
+            unblocked              bool        False: blocked record (all-zero gains)
+            mesh, face             int64       (with_geometry) triangle the ray left for the RX
+
+        nonzero_only drops the blocked records (the reference writes zeros there)."""
+        torch = self.torch
+        counts = self.counts()
+        cols = {k: [] for k in ("rx", "tx", "bounce", "path", "a_te", "a_tm", "tau", "direction_rx",
+                                "freq_shift", "unblocked")}
+        if with_geometry:
+            cols["mesh"], cols["face"] = [], []
+            T = self.num_tri
+            mesh_h, face_h = np.empty(T, np.uint32), np.empty(T, np.uint32)
+            _lib.check(self.L.hrt_problem_tri_ids(self.problem,
+                                                  mesh_h.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                  face_h.ctypes.data_as(C.POINTER(C.c_uint32))),
+                       "hrt_problem_tri_ids")
+            mesh_d = torch.from_numpy(mesh_h.astype(np.int64)).to(self.device)
+            face_d = torch.from_numpy(face_h.astype(np.int64)).to(self.device)
+        for b in range(self.nb):
+            n = int(counts[b + 1])
+            if n == 0:
+                continue
+            h = self.hits(b, n)
+            r = self.records(b, n)
+            ray = h["ray"].to(torch.int64) & 0xFFFFFFFF
+            tx, p = self.global_path(ray)
+            for rx in range(self.nrx):
+                ub = r["unblocked"][rx]
+                sel = ub if nonzero_only else torch.ones_like(ub)
+                k = int(sel.sum().item())
+                if k == 0:
+                    continue
+                cols["rx"].append(torch.full((k,), rx, dtype=torch.int64, device=self.device))
+                cols["tx"].append(tx[sel])
+                cols["bounce"].append(torch.full((k,), b, dtype=torch.int64, device=self.device))
+                cols["path"].append(p[sel])
+                cols["a_te"].append(torch.complex(r["a_te_re"][rx][sel], r["a_te_im"][rx][sel]))
+                cols["a_tm"].append(torch.complex(r["a_tm_re"][rx][sel], r["a_tm_im"][rx][sel]))
+                cols["tau"].append(r["tau"][rx][sel])
+                cols["direction_rx"].append(torch.stack([r["dirx"][rx][sel], r["diry"][rx][sel],
+                                                         r["dirz"][rx][sel]], dim=1))
+                cols["freq_shift"].append(h["fs0"][sel] - r["dfs"][rx][sel])
+                cols["unblocked"].append(ub[sel])
+                if with_geometry:
+                    tri = h["tri"].to(torch.int64)[sel] & 0xFFFFFFFF
+                    cols["mesh"].append(mesh_d[tri])
+                    cols["face"].append(face_d[tri])
+        out = {}
+        for k, v in cols.items():
+            if v:
+                out[k] = torch.cat(v)
+            else:
+                shape = (0, 3) if k == "direction_rx" else (0,)
+                dt = {"a_te": torch.complex64, "a_tm": torch.complex64, "tau": torch.float32,
+                      "direction_rx": torch.float32, "freq_shift": torch.float32,
+                      "unblocked": torch.bool}.get(k, torch.int64)
+                out[k] = torch.empty(shape, dtype=dt, device=self.device)
+        return out
+
     # ------------------------------------------------------------------ dense (host) view
     def to_dense(self, sentinel_u32=abi.SENTINEL_U32):
         """Assemble the reference's dense [rx][tx][b][p] scatter arrays on the host from the
