@@ -82,6 +82,9 @@ typedef struct {
     float *st[6];           /* o, d of the hits */
     float *rec[HRT_REC_FIELDS];
     uint64_t *mask;
+    float *rec2[HRT_REC_FIELDS];   /* second staging set: the copy of the next (bounce, rx) block */
+    uint64_t *mask2;              /* overlaps the dense scatter of the current one */
+    void *copy_stream;
     Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
     uint8_t *active, *next_active;
     float *dirs_batch;      /* gathered launch directions of one batch */
@@ -137,6 +140,10 @@ static void cache_put(uint64_t np, const float *dirs, const uint32_t *order)
 
 static void work_free(work_t *w)
 {
+    if (w->copy_stream) {   /* no copy may be in flight into the staging buffers freed below */
+        hrt_hip_stream_sync(w->copy_stream);
+        hrt_hip_stream_destroy(w->copy_stream);
+    }
     if (w->d_dirs) hrt_device_free(w->device, w->d_dirs);
     if (w->d_order) hrt_device_free(w->device, w->d_order);
     free(w->h_order);
@@ -147,6 +154,8 @@ static void work_free(work_t *w)
     for (int k = 0; k < 6; ++k) hrt_hip_host_free(w->st[k]);
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec[k]);
     hrt_hip_host_free(w->mask);
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec2[k]);
+    hrt_hip_host_free(w->mask2);
     free(w->dirs_batch); free(w->cur_rays); free(w->active); free(w->next_active);
 }
 
@@ -322,6 +331,9 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         ok &= hrt_hip_host_malloc((void **)&w.mask, cap / 64 * 8 + 8) == 0;
         for (int k = 0; k < 6 && scat_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w.st[k], cap * 4) == 0;
         for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w.rec[k], cap * 4) == 0;
+        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w.rec2[k], cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&w.mask2, cap / 64 * 8 + 8) == 0;
+        ok &= hrt_hip_stream_create(&w.copy_stream) == 0;
         if (!ok) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
     }
 
@@ -429,19 +441,41 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                     float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
                     scat->freq_shift[p] += z * prob->dop_mult;
                 }
+            /* records of (b, rx): D2H into one of two page-locked staging sets on a copy stream,
+             * so that the copy of block rx+1 runs while the host threads scatter block rx */
+#define FETCH_RX(RX, SET_REC, SET_MASK)                                                              \
+    do {                                                                                             \
+        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
+        int e_ = 0;                                                                                  \
+        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
+            e_ = hrt_hip_d2h_async((SET_REC)[k], (const uint8_t *)w.d_ws + rb_ + (uint64_t)k * L.cap * 4, H * 4, w.copy_stream); \
+        if (!e_)                                                                                     \
+            e_ = hrt_hip_d2h_async((SET_MASK), (const uint8_t *)w.d_ws + L.off_masks + ((uint64_t)b * nrx + (RX)) * (L.cap / 64) * 8, \
+                                   (H + 63) / 64 * 8, w.copy_stream);                                \
+        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
+    } while (0)
+            if (H) FETCH_RX(0, w.rec, w.mask);
             for (size_t rx = 0; rx < nrx && H; ++rx) {
-                const uint64_t rb = L.off_recs + b * L.rec_block_bytes + (uint64_t)rx * HRT_REC_FIELDS * L.cap * 4;
-                for (int k = 0; k < HRT_REC_FIELDS; ++k) DL(w.rec[k], rb + (uint64_t)k * L.cap * 4, H * 4);
-                DL(w.mask, L.off_masks + ((uint64_t)b * nrx + rx) * (L.cap / 64) * 8, (H + 63) / 64 * 8);
+                float *const *cur_rec = (rx & 1) ? w.rec2 : w.rec;
+                const uint64_t *cur_mask = (rx & 1) ? w.mask2 : w.mask;
+                {
+                    const int e = hrt_hip_stream_sync(w.copy_stream);   /* block rx has landed */
+                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
+                }
+                if (rx + 1 < nrx) {
+                    if (rx & 1) FETCH_RX(rx + 1, w.rec, w.mask);
+                    else FETCH_RX(rx + 1, w.rec2, w.mask2);
+                }
                 {
                     scatter_ctx sc;
                     memset(&sc, 0, sizeof sc);
-                    sc.s = &s; sc.ray = w.ray; sc.rec = w.rec; sc.mask = w.mask; sc.scat = scat;
+                    sc.s = &s; sc.ray = w.ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
                     sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
                     parallel_ranges(scatter_range, &sc, H, scatter_threads);
                     for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st.records_unblocked += sc.unblocked[t];
                 }
             }
+#undef FETCH_RX
 
             /* ---- RaysInfo snapshots (:732-743) ---- */
             if (scat_rays && G == 1) {

@@ -1371,6 +1371,18 @@ int hrt_hip_memset_async(void *dst, int value, uint64_t bytes, void *stream)
     return (int)hipMemsetAsync(dst, value, bytes, (hipStream_t)stream);
 }
 int hrt_hip_stream_sync(void *stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
+int hrt_hip_d2h_async(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+}
+int hrt_hip_stream_create(void **stream)
+{
+    hipStream_t s = nullptr;
+    const int rc = (int)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    *stream = (void *)s;
+    return rc;
+}
+int hrt_hip_stream_destroy(void *stream) { return (int)hipStreamDestroy((hipStream_t)stream); }
 int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b)
 {
     size_t f = 0, t = 0;

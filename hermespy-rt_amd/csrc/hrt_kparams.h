@@ -66,6 +66,9 @@ int hrt_hip_h2d(void *dst, const void *src, uint64_t bytes);
 int hrt_hip_d2h(void *dst, const void *src, uint64_t bytes);
 int hrt_hip_memset_async(void *dst, int value, uint64_t bytes, void *stream);
 int hrt_hip_stream_sync(void *stream);
+int hrt_hip_d2h_async(void *dst, const void *src, uint64_t bytes, void *stream);
+int hrt_hip_stream_create(void **stream);
+int hrt_hip_stream_destroy(void *stream);
 int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
