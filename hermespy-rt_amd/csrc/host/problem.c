@@ -528,18 +528,18 @@ int hrt_timer_read(hrt_timer *t, hrt_kernel_times *times)
 
 static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
                       const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
-                      hrt_timer *timer);
+                      hrt_timer *timer, uint32_t flags);
 
 int hrt_trace(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
               const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
               hrt_kernel_times *times)
 {
-    if (!times) return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, NULL);
+    if (!times) return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, NULL, 0);
     if (!s) return hrt_fail(HRT_E_INVALID, "hrt_trace: NULL argument");
     hrt_timer *t = NULL;
     int rc = hrt_timer_create(s->num_bounces, &t);
     if (rc) return rc;
-    rc = trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, t);
+    rc = trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, t, 0);
     if (!rc) rc = hrt_timer_read(t, times);
     hrt_timer_destroy(t);
     return rc;
@@ -550,12 +550,23 @@ int hrt_trace_timed(const hrt_problem *p, const hrt_shard *s, const float *d_dir
                     hrt_timer *timer)
 {
     if (!timer) return hrt_fail(HRT_E_INVALID, "hrt_trace_timed: NULL timer");
-    return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, timer);
+    return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, timer, 0);
+}
+
+int hrt_trace_flags(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+                    const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
+                    hrt_timer *timer, uint32_t flags)
+{
+    if (flags & ~(uint32_t)HRT_DIRS_IN_LAUNCH_ORDER)
+        return hrt_fail(HRT_E_INVALID, "hrt_trace_flags: unknown flag bits 0x%x", flags);
+    if ((flags & HRT_DIRS_IN_LAUNCH_ORDER) && !d_order)
+        return hrt_fail(HRT_E_INVALID, "HRT_DIRS_IN_LAUNCH_ORDER needs the launch order");
+    return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, timer, flags);
 }
 
 static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
                       const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
-                      hrt_timer *timer)
+                      hrt_timer *timer, uint32_t flags)
 {
     if (!p || !d_dirs || !d_ws) return hrt_fail(HRT_E_INVALID, "hrt_trace: NULL argument");
     hrt_layout L;
@@ -576,6 +587,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.fsl_mult = p->fsl_mult; K.dop_mult = p->dop_mult;
     K.dirs = d_dirs;
     K.order = d_order;
+    K.dirs_in_launch_order = (flags & HRT_DIRS_IN_LAUNCH_ORDER) ? 1u : 0u;
     K.num_local = (uint32_t)hrt_shard_num_local(s);
     K.num_bounces = s->num_bounces;
     K.n0 = p->num_tx * K.num_local;

@@ -833,7 +833,10 @@ __device__ __forceinline__ void launch_ray(const hrt_kparams &P, uint32_t i, uin
     const uint32_t il = P.order ? P.order[pos] : pos;
     ray = tx * P.num_local + il;
     o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
-    d = {P.dirs[3 * (uint64_t)il], P.dirs[3 * (uint64_t)il + 1], P.dirs[3 * (uint64_t)il + 2]};
+    // the direction table is indexed by ray id, or (HRT_DIRS_IN_LAUNCH_ORDER) already permuted into
+    // launch order: then a wave reads one contiguous 768-byte run instead of 64 scattered rows
+    const uint64_t row = P.dirs_in_launch_order ? pos : il;
+    d = {P.dirs[3 * row], P.dirs[3 * row + 1], P.dirs[3 * row + 2]};
 }
 
 // shadow ray from o towards rx (src/compute_paths.c:676-678): direction and distance

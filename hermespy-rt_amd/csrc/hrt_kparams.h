@@ -46,7 +46,7 @@ typedef struct {
     uint32_t num_local;
     uint32_t num_bounces;
     uint32_t n0;          /* num_tx * num_local */
-    uint32_t pad0;
+    uint32_t dirs_in_launch_order;   /* dirs[i] is the direction of launch position i (not of ray i) */
     /* workspace (see include/hrt_device.h) */
     uint8_t *ws;
     uint64_t cap;

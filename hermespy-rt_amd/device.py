@@ -92,6 +92,12 @@ class Tracer:
                 self.dirs = torch.from_numpy(dirs).to(self.device)
             self.order = (torch.from_numpy(self.order_host.view(np.int32)).to(self.device)
                           if coherent else None)
+            # the launch set is traced again and again: permute the direction table into launch
+            # order ONCE, so the launch kernels read contiguous runs (HRT_DIRS_IN_LAUNCH_ORDER)
+            self.flags = 0
+            if coherent:
+                self.dirs_launch = self.dirs[self.order.to(torch.int64) & 0xFFFFFFFF].contiguous()
+                self.flags = _lib.DIRS_IN_LAUNCH_ORDER
             self.ws = torch.empty(int(self.layout.total_bytes), dtype=torch.uint8, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
         self.last_times = None
@@ -115,11 +121,17 @@ class Tracer:
         torch = self.torch
         stream = torch.cuda.current_stream(self.device).cuda_stream
         times = _lib.KernelTimes() if timed else None
-        _lib.check(self.L.hrt_trace(
-            self.problem, C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()),
-            C.c_void_p(self.order.data_ptr()) if self.order is not None else None,
-            C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream),
-            C.byref(times) if timed else None), "hrt_trace")
+        if timed:
+            t = self.new_timer()
+            self.trace_with_timer(t)
+            _lib.check(self.L.hrt_timer_read(t, C.byref(times)), "hrt_timer_read")
+            self.L.hrt_timer_destroy(t)
+        else:
+            _lib.check(self.L.hrt_trace_flags(
+                self.problem, C.byref(self.shard), C.c_void_p(self._dirs_ptr()),
+                C.c_void_p(self.order.data_ptr()) if self.order is not None else None,
+                C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream),
+                None, C.c_uint32(self.flags)), "hrt_trace_flags")
         if timed:
             n = int(times.num_bounce_launches)
             self.last_times = (float(times.los_ms), [float(times.trace_ms[i]) for i in range(n)])
@@ -137,11 +149,14 @@ class Tracer:
     def trace_with_timer(self, timer):
         """Like trace(): asynchronous; HIP events around every kernel go into `timer`."""
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.L.hrt_trace_timed(
-            self.problem, C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()),
+        _lib.check(self.L.hrt_trace_flags(
+            self.problem, C.byref(self.shard), C.c_void_p(self._dirs_ptr()),
             C.c_void_p(self.order.data_ptr()) if self.order is not None else None,
-            C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream), timer),
-            "hrt_trace_timed")
+            C.c_void_p(self.ws.data_ptr()), C.c_uint64(self.ws.numel()), C.c_void_p(stream), timer,
+            C.c_uint32(self.flags)), "hrt_trace_flags")
+
+    def _dirs_ptr(self):
+        return (self.dirs_launch if self.flags & _lib.DIRS_IN_LAUNCH_ORDER else self.dirs).data_ptr()
 
     def read_timer(self, timer, destroy=True):
         """-> dict(los_ms, trace_ms[], shade_ms[], scan_ms[]); waits for the timer's last event."""

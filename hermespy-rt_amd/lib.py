@@ -18,6 +18,7 @@ EXPORTED = (
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
     "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_layout_query", "hrt_trace",
     "hrt_work_from_counts", "hrt_timer_create", "hrt_timer_destroy", "hrt_trace_timed",
+    "hrt_trace_flags",
     "hrt_timer_read", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
     "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
     "hrt_selftest_math", "hrt_debug_kernel_stats", "hrt_scene_import_sionna",
@@ -27,6 +28,7 @@ HIT_FIELDS = ("ray", "tri", "theta", "fs0", "ox", "oy", "oz", "dx", "dy", "dz",
               "a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau")
 REC_FIELDS = ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau", "dirx", "diry", "dirz", "dfs")
 LOS_FLOATS = 8
+DIRS_IN_LAUNCH_ORDER = 1   # hrt_trace_flags: dirs[i] belongs to launch position i
 
 
 class Shard(C.Structure):
@@ -123,6 +125,8 @@ def load():
     L.hrt_timer_destroy.restype = None
     L.hrt_trace_timed.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, vp]
     L.hrt_trace_timed.restype = C.c_int
+    L.hrt_trace_flags.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, vp, C.c_uint32]
+    L.hrt_trace_flags.restype = C.c_int
     L.hrt_timer_read.argtypes = [vp, C.POINTER(KernelTimes)]
     L.hrt_timer_read.restype = C.c_int
     L.hrt_work_from_counts.argtypes = [vp, C.POINTER(Shard), C.POINTER(u32), C.POINTER(Stats)]

@@ -184,6 +184,15 @@ void hrt_timer_destroy(hrt_timer *t);
 int hrt_trace_timed(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
                     const uint32_t *d_order, void *d_workspace, uint64_t workspace_bytes,
                     void *stream, hrt_timer *timer);
+
+/* hrt_trace / hrt_trace_timed (timer may be NULL) with options.  HRT_DIRS_IN_LAUNCH_ORDER: d_dirs
+ * is already permuted into launch order, d_dirs[i] = direction of ray d_order[i] (a caller that
+ * traces the same launch set repeatedly permutes once; the launch kernels then read contiguous
+ * runs instead of gathering 12-byte rows).  Results are identical. */
+#define HRT_DIRS_IN_LAUNCH_ORDER 1u
+int hrt_trace_flags(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
+                    const uint32_t *d_order, void *d_workspace, uint64_t workspace_bytes,
+                    void *stream, hrt_timer *timer, uint32_t flags);
 int hrt_timer_read(hrt_timer *t, hrt_kernel_times *out);
 
 /* Algorithmic work of a finished trace from its (host copy of) counts: see hrt_stats. */
