@@ -727,7 +727,8 @@ __device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s,
     return make_float4(te, tei, tm, tmi);
 }
 
-__device__ __noinline__ float acos_f_ool(float x) { return hrt_acosf(x); }
+// (inlined: the call sequence costs as much as the half of the function a lane runs)
+__device__ __forceinline__ float acos_f_ool(float x) { return hrt_acosf(x); }
 
 
 // Field arrays are addressed through BUFFER RESOURCES: one 128-bit descriptor (SGPRs) per block of
