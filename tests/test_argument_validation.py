@@ -1,0 +1,57 @@
+"""hrt_compute_paths_ex / hrt_problem_create validate their arguments BEFORE touching the device
+(the reference validates nothing: SURVEY Q15 asks for validation in `_ex`, behaviour in range
+unchanged): bad counts, NULL pointers, a material index beyond the 17-entry table, a vertex index
+beyond the mesh, a non-positive frequency -> HRT_E_INVALID with a message, no crash, no exit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hermespy_rt_amd import abi
+
+from . import scenes_gen as G
+
+V3 = C.POINTER(abi.Vec3)
+
+
+def _call(lib, scene, nrx=1, ntx=1, np_=100, nb=2, f=3.0, null_scene=False, null_los=False):
+    rx = np.zeros((max(nrx, 1), 3), np.float32)
+    tx = np.ones((max(ntx, 1), 3), np.float32)
+    los, scat = abi.ChannelInfo(), abi.ChannelInfo()
+    return lib.hrt_compute_paths_ex(
+        None if null_scene else C.byref(scene), rx.ctypes.data_as(V3), tx.ctypes.data_as(V3),
+        rx.ctypes.data_as(V3), tx.ctypes.data_as(V3), C.c_float(f), nrx, ntx, np_, nb,
+        None if null_los else C.byref(los), None, C.byref(scat), None, None)
+
+
+@pytest.fixture
+def scene(product_lib, tmp_path):
+    p = str(tmp_path / "s.hrt")
+    v, f = G._box([0, 0, 2], [4, 4, 4])
+    G.write_hrt(p, [dict(vs=v, idx=f, material_index=1, velocity=[0, 0, 0])])
+    s = product_lib.scene_load(p.encode())
+    yield s
+    abi.free_scene(s)
+
+
+@pytest.mark.parametrize("kw,needle", [
+    (dict(np_=0), b"num_rays"), (dict(nb=0), b"num_bounces"), (dict(nb=33), b"num_bounces"),
+    (dict(null_scene=True), b"NULL"), (dict(null_los=True), b"NULL"),
+    (dict(nrx=0), b"num_rx"), (dict(ntx=0), b"num_rx/num_tx"), (dict(f=0.0), b"frequency"),
+    (dict(f=float("nan")), b"frequency"),
+])
+def test_bad_arguments_are_refused(product_lib, scene, kw, needle):
+    assert _call(product_lib, scene, **kw) == -1          # HRT_E_INVALID
+    assert needle in product_lib.hrt_last_error()
+
+
+def test_bad_material_and_vertex_indices_are_refused(product_lib, scene):
+    m = scene.meshes[0]
+    keep = m.material_index
+    m.material_index = 17
+    assert _call(product_lib, scene) == -1 and b"material_index" in product_lib.hrt_last_error()
+    m.material_index = keep
+    old = m.is_[5]
+    m.is_[5] = m.num_vertices          # one past the last vertex
+    assert _call(product_lib, scene) == -1 and b"vertex index" in product_lib.hrt_last_error()
+    m.is_[5] = old
