@@ -37,3 +37,17 @@ def test_random_config(product_lib, seed):
     ref = oracle.compute_paths(*K.args(c))
     st = compare_dense(got, ref)
     assert all(v == 0 for v in st.values()), st
+
+
+@pytest.mark.parametrize("nrx,ntx", [(40, 1), (70, 2)])
+def test_many_receivers(product_lib, nrx, ntx):
+    """More receivers than lanes in a wave / than any bundled configuration: the shadow-trace
+    kinds, the theta carry across the RX loop and the per-RX record blocks scale with num_rx."""
+    rng = np.random.default_rng(5 + nrx)
+    lo, hi = BOUNDS["simple_street_canyon_with_cars.hrt"]
+    c = K.cfg("simple_street_canyon_with_cars.hrt", rng.uniform(lo, hi, (nrx, 3)).tolist(),
+              rng.uniform(lo, hi, (ntx, 3)).tolist(), 3.5, 700, 3)
+    got = abi.run_compute_paths(product_lib, *K.args(c))
+    ref = oracle.compute_paths(*K.args(c))
+    st = compare_dense(got, ref)
+    assert all(v == 0 for v in st.values()), st
