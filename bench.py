@@ -285,6 +285,15 @@ def main():
             traffic_src = pj[args.workload]["source"]
     except (OSError, ValueError, KeyError):
         pass
+    # VALU issue utilisation of the two kernels (SURVEY 8d asks for the VALU fraction next to the
+    # HBM one): from profiles/collect_valu.sh (own rocprofv3 --pmc pass), same workload, N = 1
+    valu = None
+    try:
+        vj = json.load(open(os.path.join(REPO, "profiles", "pmc_valu.json")))
+        if world == 1 and args.workload in vj:
+            valu = dict(vj[args.workload]["kernels"], source=vj[args.workload]["source"])
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = dict(bound="hbm", kernel="hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)",
                     achieved=ach, peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
@@ -296,6 +305,7 @@ def main():
                     kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
                     compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
                     trace_variant=os.environ.get("HRT_TRACE_VARIANT", "default(2: packet culling)"),
+                    valu=valu,
                     note="VALU-bound intersection work, not HBM-bound: see DESIGN.md section 6")
 
     kstats = None

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""profiles/collect_valu.sh -> profiles/<tag>_pmc_valu_<workload>.csv (trimmed to our kernels) and
+profiles/pmc_valu.json: VALU instructions per step and the VALU issue fraction of the trace and
+the shade kernel, which bench.py reports next to the HBM roofline (roofline.valu)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+workload = sys.argv[2] if len(sys.argv) > 2 else "c3"
+SIMDS = 256 * 4
+XCDS = 8   # GRBM_GUI_ACTIVE comes back summed over the 8 XCD instances (8x kernel time x clock)
+
+f = max(glob.glob(os.path.join(REPO, "gpurun_out", "pmc_%s_VALU" % tag, "*", "*counter_collection.csv")),
+        key=os.path.getmtime)
+rows = [r for r in csv.DictReader(open(f)) if "hrt_" in r["Kernel_Name"]]
+keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "VGPR_Count", "Counter_Name", "Counter_Value"]
+with open(os.path.join(HERE, "%s_pmc_valu_%s.csv" % (tag, workload)), "w", newline="") as fo:
+    w = csv.DictWriter(fo, keep)
+    w.writeheader()
+    for r in rows:
+        w.writerow({k: r[k] for k in keep})
+n_steps = len({r["Dispatch_Id"] for r in rows if "los" in r["Kernel_Name"]})
+out = {}
+for kern in ("trace", "shade"):
+    acc = {}
+    for r in rows:
+        if kern in r["Kernel_Name"]:
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    insts, cyc = acc["SQ_INSTS_VALU"] / n_steps, acc["GRBM_GUI_ACTIVE"] / n_steps
+    out[kern] = dict(valu_insts_per_step=insts, busy_cycles_per_step_per_xcd=cyc / XCDS, issue_frac=insts * 4.0 / (SIMDS * cyc / XCDS))
+path = os.path.join(HERE, "pmc_valu.json")
+allj = json.load(open(path)) if os.path.exists(path) else {}
+allj[workload] = dict(round=tag, kernels=out,
+                      source="rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES (profiles/%s_pmc_valu_%s.csv); "
+                             "issue_frac = insts * 4 cycles / (1024 SIMDs * busy cycles per XCD); f64 instructions "
+                             "(shade kernel) occupy 8 cycles, so its figure is a lower bound" % (tag, workload))
+json.dump(allj, open(path, "w"), indent=1)
+print(json.dumps(allj[workload], indent=1))
