@@ -1343,6 +1343,13 @@ static void launch_trace_t(const hrt_kparams *P, uint32_t bounce, uint32_t block
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (*err != hipSuccess) return;
     }
+    static const bool report = getenv("HRT_DEBUG_OCCUPANCY") != nullptr;
+    if (report && bounce == 1) {   // diagnostic: resident workgroups per CU at this LDS size
+        int nblk = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, hrt_trace_kernel<LDS, V>, HRT_BLOCK, lds);
+        fprintf(stderr, "hrt_trace_kernel: %d workgroups of %u threads per CU at %zu bytes of LDS\n", nblk,
+                HRT_BLOCK, lds);
+    }
     hipLaunchKernelGGL((hrt_trace_kernel<LDS, V>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P,
                        bounce);
 }

@@ -1,10 +1,9 @@
 #!/bin/bash
-# VALU issue utilisation of the two kernels from PMC counters (own rocprofv3 pass, --kernel-trace
-# only beside --pmc): SQ_INSTS_VALU = VALU instructions issued (per wave), GRBM_GUI_ACTIVE = cycles
-# the GPU was busy during the dispatch.  A wave64 VALU instruction occupies its SIMD for 4 cycles,
-# an MI355X has 256 CUs x 4 SIMDs, so   issue fraction = SQ_INSTS_VALU * 4 / (1024 * GRBM_GUI_ACTIVE / 8)
-# (the counter comes back summed over the 8 XCDs)
-# (double-precision instructions take 8 cycles: the shade kernel's figure is a lower bound).
+# VALU issue rate of the two kernels from PMC counters (own rocprofv3 pass, --kernel-trace only
+# beside --pmc): SQ_INSTS_VALU = VALU instructions issued (per wave), GRBM_GUI_ACTIVE = busy cycles
+# of the dispatch (summed over the 8 XCDs).  cycles per VALU instruction per SIMD =
+# 1024 SIMDs * (GRBM_GUI_ACTIVE / 8) / SQ_INSTS_VALU; the SIMD-32's own rate is 2 cycles per wave64
+# instruction, what a busy chip sustains per instruction class is in profiles/microbench/.
 # Run on the GPU box from the repo root:   bash profiles/collect_valu.sh <tag>
 # then, back home:                          python profiles/parse_valu.py <tag>
 set -e

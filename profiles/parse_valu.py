@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/collect_valu.sh -> profiles/<tag>_pmc_valu_<workload>.csv (trimmed to our kernels) and
-profiles/pmc_valu.json: VALU instructions per step and the VALU issue fraction of the trace and
-the shade kernel, which bench.py reports next to the HBM roofline (roofline.valu)."""
+profiles/pmc_valu.json: VALU instructions per step and SIMD-cycles per VALU instruction of the trace
+and the shade kernel, which bench.py reports next to the HBM roofline (roofline.valu)."""
 import csv
 import glob
 import json
@@ -32,12 +32,15 @@ for kern in ("trace", "shade"):
         if kern in r["Kernel_Name"]:
             acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     insts, cyc = acc["SQ_INSTS_VALU"] / n_steps, acc["GRBM_GUI_ACTIVE"] / n_steps
-    out[kern] = dict(valu_insts_per_step=insts, busy_cycles_per_step_per_xcd=cyc / XCDS, issue_frac=insts * 4.0 / (SIMDS * cyc / XCDS))
+    out[kern] = dict(valu_insts_per_step=insts, busy_cycles_per_step_per_xcd=cyc / XCDS, cycles_per_valu_inst=SIMDS * (cyc / XCDS) / insts,
+                     issue_frac_vs_simd32_peak=insts * 2.0 / (SIMDS * cyc / XCDS))
 path = os.path.join(HERE, "pmc_valu.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[workload] = dict(round=tag, kernels=out,
                       source="rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES (profiles/%s_pmc_valu_%s.csv); "
-                             "issue_frac = insts * 4 cycles / (1024 SIMDs * busy cycles per XCD); f64 instructions "
-                             "(shade kernel) occupy 8 cycles, so its figure is a lower bound" % (tag, workload))
+                             "cycles_per_valu_inst = 1024 SIMDs * busy cycles per XCD / insts; the SIMD-32 peak is "
+                             "2 cycles per wave64 instruction, a busy chip sustains 2.3-2.9 on fma/mul/add, 4.2 on "
+                             "compares/min/max/DPP, 8.1 on transcendentals, 5.2 on f64 fma "
+                             "(profiles/microbench/r01_valu_issue.txt)" % (tag, workload))
 json.dump(allj, open(path, "w"), indent=1)
 print(json.dumps(allj[workload], indent=1))
