@@ -223,3 +223,59 @@ def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nu
 def written(a):
     """Boolean mask of slots whose bit pattern is not the sentinel."""
     return a.view(np.uint32) != SENTINEL_U32
+
+
+class PathList(C.Structure):
+    """include/hermespy_rt.h hrt_path_list"""
+    _fields_ = [
+        ("num", C.c_uint64), ("num_rx", C.c_uint32), ("num_tx", C.c_uint32),
+        ("rx", C.POINTER(C.c_uint32)), ("tx", C.POINTER(C.c_uint32)), ("bounce", C.POINTER(C.c_uint32)),
+        ("path", C.POINTER(C.c_uint64)),
+        ("a_te_re", c_float_p), ("a_te_im", c_float_p), ("a_tm_re", c_float_p), ("a_tm_im", c_float_p),
+        ("tau", c_float_p), ("direction_rx", C.POINTER(Vec3)), ("freq_shift", c_float_p),
+        ("unblocked", C.POINTER(C.c_uint8)), ("mesh", C.POINTER(C.c_uint32)), ("face", C.POINTER(C.c_uint32)),
+        ("los", c_float_p),
+    ]
+
+
+def run_compute_paths_list(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
+                           num_bounces, include_blocked=False, stats=None):
+    """hrt_compute_paths_list through ctypes -> dict of numpy arrays (copies; the C list is freed)."""
+    rx_pos = np.asarray(rx_pos, np.float32).reshape(-1, 3)
+    tx_pos = np.asarray(tx_pos, np.float32).reshape(-1, 3)
+    nrx, ntx = rx_pos.shape[0], tx_pos.shape[0]
+    _, rxp = _vec3_arg(rx_pos, nrx)
+    _, txp = _vec3_arg(tx_pos, ntx)
+    rxv_a, rxv = _vec3_arg(rx_vel, nrx)
+    txv_a, txv = _vec3_arg(tx_vel, ntx)
+    lib.hrt_compute_paths_list.restype = C.c_int
+    lib.hrt_path_list_free.restype = None
+    pl = PathList()
+    scene = lib.scene_load(str(scene_path).encode())
+    try:
+        rc = lib.hrt_compute_paths_list(C.byref(scene), rxp, txp, rxv, txv, C.c_float(f_ghz),
+                                        C.c_size_t(nrx), C.c_size_t(ntx), C.c_size_t(int(num_paths)),
+                                        C.c_size_t(int(num_bounces)), C.c_int(1 if include_blocked else 0),
+                                        C.byref(pl), C.byref(stats) if stats is not None else None)
+        if rc != 0:
+            raise RuntimeError("hrt_compute_paths_list failed (%d): %s" % (rc, lib.hrt_last_error().decode()))
+        n = int(pl.num)
+
+        def arr(ptr, dtype, shape):
+            if n == 0:
+                return np.zeros(shape, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)),
+                                         shape=(int(np.prod(shape)) * np.dtype(dtype).itemsize,)).view(dtype).reshape(shape).copy()
+
+        out = dict(rx=arr(pl.rx, np.uint32, (n,)), tx=arr(pl.tx, np.uint32, (n,)),
+                   bounce=arr(pl.bounce, np.uint32, (n,)), path=arr(pl.path, np.uint64, (n,)),
+                   tau=arr(pl.tau, np.float32, (n,)), direction_rx=arr(pl.direction_rx, np.float32, (n, 3)),
+                   freq_shift=arr(pl.freq_shift, np.float32, (n,)), unblocked=arr(pl.unblocked, np.uint8, (n,)).astype(bool),
+                   mesh=arr(pl.mesh, np.uint32, (n,)), face=arr(pl.face, np.uint32, (n,)))
+        for k in ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im"):
+            out[k] = arr(getattr(pl, k), np.float32, (n,))
+        out["los"] = np.ctypeslib.as_array(pl.los, shape=(nrx * ntx * 8,)).copy().reshape(nrx, ntx, 8)
+    finally:
+        lib.hrt_path_list_free(C.byref(pl))
+        free_scene(scene)
+    return out

@@ -31,7 +31,7 @@
 
 /* ---- a minimal parallel-for over [0, n): the dense scatter is host-memory bound and every
  * record owns its slots, so it splits into independent ranges ---- */
-typedef void (*range_fn)(void *ctx, uint64_t i0, uint64_t i1, int tid);
+typedef hrt_range_fn range_fn;
 typedef struct { range_fn fn; void *ctx; uint64_t i0, i1; int tid; } range_job;
 static void *range_thread(void *a)
 {
@@ -39,8 +39,7 @@ static void *range_thread(void *a)
     j->fn(j->ctx, j->i0, j->i1, j->tid);
     return NULL;
 }
-#define HRT_MAX_SCATTER_THREADS 32
-static void parallel_ranges(range_fn fn, void *ctx, uint64_t n, int threads)
+void hrt_parallel_ranges(hrt_range_fn fn, void *ctx, uint64_t n, int threads)
 {
     if (threads > HRT_MAX_SCATTER_THREADS) threads = HRT_MAX_SCATTER_THREADS;
     if ((uint64_t)threads > n / 65536 + 1) threads = (int)(n / 65536 + 1);
@@ -58,6 +57,17 @@ static void parallel_ranges(range_fn fn, void *ctx, uint64_t n, int threads)
         ++started;
     }
     for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+}
+
+int hrt_host_threads(void)
+{
+    const char *v = getenv("HRT_HOST_THREADS");
+    int t = (v && *v) ? atoi(v) : 0;
+    if (t <= 0) {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        t = nc > 16 ? 16 : (nc > 0 ? (int)nc : 1);
+    }
+    return t;
 }
 
 static int env_int(const char *name, int dflt)
@@ -108,10 +118,10 @@ void hrt_cache_clear(void)
     pthread_mutex_unlock(&g_cache_lock);
 }
 
-static int cache_enabled(uint64_t np) { return !env_int("HRT_NO_CACHE", 0) && np * 16 <= (1ull << 30); }
+int hrt_launch_cache_enabled(uint64_t np) { return !env_int("HRT_NO_CACHE", 0) && np * 16 <= (1ull << 30); }
 
 /* copies of the cached tables for `np` into dirs / order (either may be NULL); 1 if served */
-static int cache_get(uint64_t np, float *dirs, uint32_t *order)
+int hrt_launch_cache_get(uint64_t np, float *dirs, uint32_t *order)
 {
     int hit = 0;
     pthread_mutex_lock(&g_cache_lock);
@@ -124,9 +134,9 @@ static int cache_get(uint64_t np, float *dirs, uint32_t *order)
     return hit;
 }
 
-static void cache_put(uint64_t np, const float *dirs, const uint32_t *order)
+void hrt_launch_cache_put(uint64_t np, const float *dirs, const uint32_t *order)
 {
-    if (!cache_enabled(np)) return;
+    if (!hrt_launch_cache_enabled(np)) return;
     pthread_mutex_lock(&g_cache_lock);
     if (g_cache.np != np) {
         free(g_cache.dirs); free(g_cache.order);
@@ -223,11 +233,7 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     if (rc) return rc;
     const uint32_t T = prob->num_tri;
     const size_t nq = ntx * np;
-    int scatter_threads = env_int("HRT_HOST_THREADS", 0);
-    if (scatter_threads <= 0) {
-        long nc = sysconf(_SC_NPROCESSORS_ONLN);
-        scatter_threads = nc > 16 ? 16 : (nc > 0 ? (int)nc : 1);
-    }
+    const int scatter_threads = hrt_host_threads();
 
     /* normals: the reference leaves them in the scene for the caller (:208-224) */
     {
@@ -248,10 +254,10 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     hrt_shard whole = {np, 0, 1, 0, (uint32_t)nb};
     w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
     if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-    if (!(cache_enabled(np) && cache_get(np, w.h_dirs, NULL))) {
+    if (!(hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, w.h_dirs, NULL))) {
         rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
         if (rc) goto done;
-        cache_put(np, w.h_dirs, NULL);
+        hrt_launch_cache_put(np, w.h_dirs, NULL);
     }
     st.t_launch_dirs_s = hrt_now_s() - t0;
 
@@ -355,9 +361,9 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             src = w.dirs_batch;
         }
         t0 = hrt_now_s();
-        if (!(G == 1 && cache_enabled(np) && cache_get(np, NULL, w.h_order))) {
+        if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, NULL, w.h_order))) {
             if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
-            if (G == 1) cache_put(np, w.h_dirs, w.h_order);
+            if (G == 1) hrt_launch_cache_put(np, w.h_dirs, w.h_order);
         }
         st.t_launch_dirs_s += hrt_now_s() - t0;   /* host-side launch preparation */
         t0 = hrt_now_s();
@@ -471,7 +477,7 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                     memset(&sc, 0, sizeof sc);
                     sc.s = &s; sc.ray = w.ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
                     sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
-                    parallel_ranges(scatter_range, &sc, H, scatter_threads);
+                    hrt_parallel_ranges(scatter_range, &sc, H, scatter_threads);
                     for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st.records_unblocked += sc.unblocked[t];
                 }
             }

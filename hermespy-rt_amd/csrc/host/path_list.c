@@ -1,0 +1,297 @@
+/* path_list.c -- hrt_compute_paths_list(): compute_paths() with the result as ONE list of path
+ * records instead of the reference's dense [rx][tx][bounce][path] arrays.
+ *
+ * Same inputs and the same tracing as the drop-in compute_paths (csrc/host/compute_paths.c; the
+ * reference's src/compute_paths.c:419-757), same values bit for bit; what differs is the output
+ * side: the dense form is > 95 % unwritten slots (C3: 2.3 GB of caller arrays for 23 M non-zero
+ * records, most of a warm call's time goes into page-faulting them in), the list holds exactly the
+ * records, each with the indices of the dense slot it would occupy.  Built on the public
+ * device-resident API (include/hrt_device.h) only.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+
+#include "hrt_internal.h"
+
+static uint64_t pl_env_u64(const char *name, uint64_t dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? (uint64_t)strtoull(v, NULL, 10) : dflt;
+}
+
+void hrt_path_list_free(hrt_path_list *pl)
+{
+    if (!pl) return;
+    free(pl->rx); free(pl->tx); free(pl->bounce); free(pl->path);
+    free(pl->a_te_re); free(pl->a_te_im); free(pl->a_tm_re); free(pl->a_tm_im); free(pl->tau);
+    free(pl->direction_rx); free(pl->freq_shift); free(pl->unblocked); free(pl->mesh); free(pl->face);
+    free(pl->los);
+    memset(pl, 0, sizeof *pl);
+}
+
+static int pl_reserve(hrt_path_list *pl, uint64_t *cap, uint64_t need)
+{
+    if (need <= *cap) return HRT_OK;
+    uint64_t nc = *cap ? *cap : 1024;
+    while (nc < need) nc += nc / 2 + 1024;
+    /* 2 MiB-aligned blocks advised to use huge pages: the list is written once, front to back, by
+     * several threads, and with 4 KiB pages most of that time is page faults (free() releases
+     * posix_memalign memory; the advice is only a hint) */
+#define GROW(field, type)                                                        \
+    do {                                                                         \
+        void *q_ = NULL;                                                         \
+        const size_t bytes_ = (((size_t)nc * sizeof(type)) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); \
+        if (posix_memalign(&q_, (size_t)2 << 20, bytes_) != 0 || !q_)           \
+            return hrt_fail(HRT_E_NOMEM, "out of host memory");                  \
+        (void)madvise(q_, bytes_, MADV_HUGEPAGE);                                \
+        if (pl->field) {                                                         \
+            memcpy(q_, pl->field, (size_t)pl->num * sizeof(type));               \
+            free(pl->field);                                                     \
+        }                                                                        \
+        pl->field = (type *)q_;                                                  \
+    } while (0)
+    GROW(rx, uint32_t); GROW(tx, uint32_t); GROW(bounce, uint32_t); GROW(path, uint64_t);
+    GROW(a_te_re, float); GROW(a_te_im, float); GROW(a_tm_re, float); GROW(a_tm_im, float);
+    GROW(tau, float); GROW(direction_rx, Vec3); GROW(freq_shift, float); GROW(unblocked, uint8_t);
+    GROW(mesh, uint32_t); GROW(face, uint32_t);
+#undef GROW
+    *cap = nc;
+    return HRT_OK;
+}
+
+/* one (bounce, rx) block of H records -> entries [base + offset of the range ...) of the list */
+typedef struct {
+    hrt_path_list *out;
+    const hrt_shard *s;
+    const hrt_problem *prob;
+    const uint32_t *ray, *tri;
+    const float *fs0;
+    float *const *field;
+    const uint64_t *mask;
+    uint64_t n_loc, base;
+    uint32_t rx, bounce;
+    int include_blocked;
+    uint64_t start[HRT_MAX_SCATTER_THREADS + 1];   /* first output entry of every range */
+    uint64_t i0[HRT_MAX_SCATTER_THREADS], i1[HRT_MAX_SCATTER_THREADS];
+} fill_ctx;
+
+static uint64_t count_bits(const uint64_t *mask, uint64_t i0, uint64_t i1)
+{
+    uint64_t n = 0;
+    for (uint64_t i = i0; i < i1;) {
+        if ((i & 63) == 0 && i + 64 <= i1) { n += (uint64_t)__builtin_popcountll(mask[i >> 6]); i += 64; }
+        else { n += (mask[i >> 6] >> (i & 63)) & 1u; ++i; }
+    }
+    return n;
+}
+
+static void fill_one(fill_ctx *c, int tid)
+{
+    hrt_path_list *out = c->out;
+    uint64_t n = c->base + c->start[tid];
+    for (uint64_t i = c->i0[tid]; i < c->i1[tid]; ++i) {
+        const int ub = (int)((c->mask[i >> 6] >> (i & 63)) & 1u);
+        if (!ub && !c->include_blocked) continue;
+        const uint32_t ql = c->ray[i];
+        const uint32_t tx = (uint32_t)(ql / c->n_loc);
+        out->rx[n] = c->rx;
+        out->tx[n] = tx;
+        out->bounce[n] = c->bounce;
+        out->path[n] = hrt_shard_global_path(c->s, ql - (uint64_t)tx * c->n_loc);
+        out->a_te_re[n] = c->field[HRT_REC_A_TE_RE][i];
+        out->a_te_im[n] = c->field[HRT_REC_A_TE_IM][i];
+        out->a_tm_re[n] = c->field[HRT_REC_A_TM_RE][i];
+        out->a_tm_im[n] = c->field[HRT_REC_A_TM_IM][i];
+        out->tau[n] = c->field[HRT_REC_TAU][i];
+        out->direction_rx[n] = (Vec3){c->field[HRT_REC_DIRX][i], c->field[HRT_REC_DIRY][i],
+                                      c->field[HRT_REC_DIRZ][i]};
+        out->freq_shift[n] = c->fs0[i] - c->field[HRT_REC_DFS][i];
+        out->unblocked[n] = (uint8_t)ub;
+        out->mesh[n] = c->prob->h_tri_mesh[c->tri[i]];
+        out->face[n] = c->prob->h_tri_face[c->tri[i]];
+        ++n;
+    }
+}
+
+/* hrt_parallel_ranges splits [0, nt * 65536): slice k of it stands for prepared range k (a thread
+ * that could not be started leaves several slices to one caller) */
+static void fill_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    (void)tid;
+    for (uint64_t k = i0 / 65536; k < i1 / 65536; ++k) fill_one((fill_ctx *)vctx, (int)k);
+}
+
+int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos, const Vec3 *rx_vel,
+                           const Vec3 *tx_vel, float f_ghz, size_t nrx, size_t ntx, size_t np,
+                           size_t nb, int include_blocked, hrt_path_list *out, hrt_stats *stats)
+{
+    const double t_begin = hrt_now_s();
+    if (!scene || !out) return hrt_fail(HRT_E_INVALID, "hrt_compute_paths_list: NULL argument");
+    if (np == 0 || nb == 0) return hrt_fail(HRT_E_INVALID, "num_rays and num_bounces must be > 0");
+    if (nb > 32) return hrt_fail(HRT_E_INVALID, "num_bounces > 32 is not supported");
+    memset(out, 0, sizeof *out);
+
+    const int device = (int)pl_env_u64("HRT_DEVICE", 0);
+    hrt_stats st;
+    memset(&st, 0, sizeof st);
+    st.device = device;
+    hrt_problem *prob = NULL;
+    int rc = hrt_problem_create(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, device, &prob);
+    if (rc) return rc;
+    st.t_setup_s = hrt_now_s() - t_begin;
+
+    void *d_ws = NULL, *d_dirs = NULL, *d_order = NULL;
+    float *h_dirs = NULL, *h_field[HRT_REC_FIELDS] = {0}, *h_fs0 = NULL;
+    uint32_t *h_order = NULL, *h_ray = NULL, *h_tri = NULL, *h_counts = NULL;
+    uint64_t *h_mask = NULL;
+    uint64_t cap_out = 0;
+    const int threads = hrt_host_threads();
+    double t_dev = 0.0, t_rb = 0.0, t_dirs = 0.0;
+
+    /* batches of round-robin shards so that one workspace fits the budget (as the drop-in does) */
+    uint64_t free_b = 0, total_b = 0;
+    if ((rc = hrt_device_mem_info(device, &free_b, &total_b))) goto done;
+    uint64_t budget = pl_env_u64("HRT_WORKSPACE_BYTES", 0);
+    if (!budget) {
+        budget = free_b / 2;
+        if (budget > (16ull << 30)) budget = 16ull << 30;
+    }
+    uint32_t G = 1;
+    hrt_layout L;
+    for (;;) {
+        hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
+        rc = hrt_layout_query(prob, &s, &L);
+        if (rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 16 <= budget) break;
+        if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
+        if ((uint64_t)G * 4096 >= np) {
+            if (rc == HRT_OK) break;
+            goto done;
+        }
+        G *= 2;
+    }
+    {
+        hrt_shard s0 = {np, 0, G, 0, (uint32_t)nb};
+        if ((rc = hrt_layout_query(prob, &s0, &L))) goto done;
+        const uint64_t n0 = hrt_shard_num_local(&s0), cap = L.cap;
+        if ((rc = hrt_device_malloc(device, &d_ws, L.total_bytes))) goto done;
+        if ((rc = hrt_device_malloc(device, &d_dirs, n0 * 12))) goto done;
+        if ((rc = hrt_device_malloc(device, &d_order, n0 * 4))) goto done;
+        h_dirs = (float *)malloc(n0 * 12);
+        h_order = (uint32_t *)malloc(n0 * 4);
+        h_counts = (uint32_t *)calloc(nb + 2, 4);
+        int ok = h_dirs && h_order && h_counts;
+        /* D2H staging is page-locked (hipHostMalloc): 2-4x the pageable copy rate */
+        ok &= hrt_hip_host_malloc((void **)&h_ray, cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&h_tri, cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&h_fs0, cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&h_mask, cap / 64 * 8 + 8) == 0;
+        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&h_field[k], cap * 4) == 0;
+        out->los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+        if (!ok || !out->los) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+    }
+    out->num_rx = (uint32_t)nrx;
+    out->num_tx = (uint32_t)ntx;
+
+#define DLP(dst, off, bytes)                                                                    \
+    do {                                                                                        \
+        if ((rc = hrt_device_download(device, (dst), (const uint8_t *)d_ws + (off), (bytes)))) goto done; \
+    } while (0)
+
+    for (uint32_t g = 0; g < G; ++g) {
+        hrt_shard s = {np, g, G, 0, (uint32_t)nb};
+        const uint64_t n_loc = hrt_shard_num_local(&s);
+        if (n_loc == 0) continue;
+        if ((rc = hrt_layout_query(prob, &s, &L))) goto done;
+        double t0 = hrt_now_s();
+        if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, h_dirs, h_order))) {
+            if ((rc = hrt_launch_dirs_host(&s, h_dirs, 0))) goto done;
+            if ((rc = hrt_launch_order_host(&s, h_dirs, h_order))) goto done;
+            if (G == 1) hrt_launch_cache_put(np, h_dirs, h_order);
+        }
+        t_dirs += hrt_now_s() - t0;
+        t0 = hrt_now_s();
+        if ((rc = hrt_device_upload(device, d_dirs, h_dirs, n_loc * 12))) goto done;
+        if ((rc = hrt_device_upload(device, d_order, h_order, n_loc * 4))) goto done;
+        if ((rc = hrt_trace(prob, &s, (const float *)d_dirs, (const uint32_t *)d_order, d_ws,
+                            L.total_bytes, NULL, NULL))) goto done;
+        if ((rc = hrt_device_sync(device, NULL))) goto done;
+        t_dev += hrt_now_s() - t0;
+
+        t0 = hrt_now_s();
+        DLP(h_counts, L.off_counts, (nb + 2) * 4);
+        if (h_counts[nb + 1] != 0) {
+            rc = hrt_fail(HRT_E_HIP, "device reported internal error flags %u", h_counts[nb + 1]);
+            goto done;
+        }
+        {
+            hrt_stats bs;
+            hrt_work_from_counts(prob, &s, h_counts, &bs);
+            for (size_t b = 0; b <= nb; ++b) st.live[b] += bs.live[b];
+            st.records += bs.records;
+            st.tests += bs.tests - (g ? (uint64_t)nrx * ntx * prob->num_tri : 0);
+        }
+        if (g == 0) DLP(out->los, L.off_los, nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+        {   /* room for every record of this batch (exact with include_blocked, <= 1.2x otherwise) */
+            uint64_t recs = 0;
+            for (size_t b = 0; b < nb; ++b) recs += (uint64_t)nrx * h_counts[b + 1];
+            if ((rc = pl_reserve(out, &cap_out, out->num + recs))) goto done;
+        }
+        for (size_t b = 0; b < nb; ++b) {
+            const uint64_t H = h_counts[b + 1];
+            if (!H) continue;
+            const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
+            DLP(h_ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
+            DLP(h_tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
+            DLP(h_fs0, hb + (uint64_t)HRT_HIT_FS0 * L.cap * 4, H * 4);
+            for (size_t rx = 0; rx < nrx; ++rx) {
+                const uint64_t rb = L.off_recs + b * L.rec_block_bytes + (uint64_t)rx * HRT_REC_FIELDS * L.cap * 4;
+                for (int k = 0; k < HRT_REC_FIELDS; ++k) DLP(h_field[k], rb + (uint64_t)k * L.cap * 4, H * 4);
+                DLP(h_mask, L.off_masks + ((uint64_t)b * nrx + rx) * (L.cap / 64) * 8, (H + 63) / 64 * 8);
+                {
+                    fill_ctx fc;
+                    memset(&fc, 0, sizeof fc);
+                    fc.out = out; fc.s = &s; fc.prob = prob; fc.ray = h_ray; fc.tri = h_tri; fc.fs0 = h_fs0;
+                    fc.field = h_field; fc.mask = h_mask; fc.n_loc = n_loc; fc.base = out->num;
+                    fc.rx = (uint32_t)rx; fc.bounce = (uint32_t)b; fc.include_blocked = include_blocked;
+                    int nt = threads;
+                    if ((uint64_t)nt > H / 65536 + 1) nt = (int)(H / 65536 + 1);
+                    uint64_t total = 0, unb = 0;
+                    for (int t = 0; t < nt; ++t) {
+                        /* ranges on 64-entry boundaries, so that no mask word is shared */
+                        fc.i0[t] = (H * (uint64_t)t / (uint64_t)nt) & ~63ull;
+                        fc.i1[t] = (t + 1 == nt) ? H : ((H * (uint64_t)(t + 1) / (uint64_t)nt) & ~63ull);
+                        const uint64_t u = count_bits(h_mask, fc.i0[t], fc.i1[t]);
+                        fc.start[t] = total;
+                        total += include_blocked ? fc.i1[t] - fc.i0[t] : u;
+                        unb += u;
+                    }
+                    st.records_unblocked += unb;
+                    /* one range per thread: hrt_parallel_ranges(n = nt, threads = nt) */
+                    hrt_parallel_ranges(fill_range, &fc, (uint64_t)nt * 65536, nt);
+                    out->num += total;
+                }
+            }
+        }
+        t_rb += hrt_now_s() - t0;
+    }
+#undef DLP
+    st.t_launch_dirs_s = t_dirs;
+    st.t_device_s = t_dev;
+    st.t_readback_s = t_rb;
+    st.t_total_s = hrt_now_s() - t_begin;
+    if (stats) *stats = st;
+    rc = HRT_OK;
+
+done:
+    if (d_ws) hrt_device_free(device, d_ws);
+    if (d_dirs) hrt_device_free(device, d_dirs);
+    if (d_order) hrt_device_free(device, d_order);
+    free(h_dirs); free(h_order); free(h_counts);
+    hrt_hip_host_free(h_ray); hrt_hip_host_free(h_tri); hrt_hip_host_free(h_fs0); hrt_hip_host_free(h_mask);
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(h_field[k]);
+    hrt_problem_destroy(prob);
+    if (rc != HRT_OK) hrt_path_list_free(out);
+    return rc;
+}

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libhermespy_rt_amd.so")
 
 #: every symbol include/hermespy_rt.h and include/hrt_device.h declare
 EXPORTED = (
-    "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_last_error",
+    "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_compute_paths_list",
+    "hrt_path_list_free", "hrt_last_error",
     "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",

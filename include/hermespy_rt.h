@@ -123,6 +123,36 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
 #define HRT_E_HIP (-3)       /* HIP runtime error; text via hrt_last_error() */
 #define HRT_E_CAPACITY (-4)  /* problem does not fit the device / > 71.5 M rays in one shard */
 
+/* compute_paths() with the result as ONE list of path records instead of dense arrays: same inputs,
+ * same tracing, the same values bit for bit (src/compute_paths.c:419-757), but only the records
+ * that exist -- the dense [rx][tx][bounce][path] form is > 95 % unwritten slots.  Entry n is the
+ * record the reference would write at scat.*[((rx[n]*num_tx + tx[n])*num_bounces + bounce[n])*
+ * num_rays + path[n]]; order: by bounce, then rx, then the device's live-list order.
+ * freq_shift = launch Doppler term of the ray minus the record's (the dense array's value for one
+ * TX; the reference's dense fill is undefined for more).  All arrays are malloc'ed by the
+ * call and released by hrt_path_list_free(). */
+typedef struct {
+    uint64_t num;
+    uint32_t num_rx, num_tx;
+    uint32_t *rx, *tx, *bounce;      /* [num] */
+    uint64_t *path;                  /* [num] */
+    float *a_te_re, *a_te_im, *a_tm_re, *a_tm_im, *tau;   /* [num]; a blocked record has zeros */
+    Vec3 *direction_rx;              /* [num]; undefined for blocked records */
+    float *freq_shift;               /* [num]; undefined for blocked records */
+    uint8_t *unblocked;              /* [num] */
+    uint32_t *mesh, *face;           /* [num] the triangle the ray left towards the RX */
+    float *los;                      /* [num_rx*num_tx][8]: u32 status (0 coincident, 1 blocked,
+                                      * 2 clear), a, tau, dir_tx xyz, freq_shift, - (HRT_LOS_*) */
+} hrt_path_list;
+
+/* include_blocked = 0 drops the blocked records (the reference writes zeros there). */
+int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_positions, const Vec3 *tx_positions,
+                           const Vec3 *rx_velocities, const Vec3 *tx_velocities,
+                           float carrier_frequency_GHz, size_t num_rx, size_t num_tx, size_t num_rays,
+                           size_t num_bounces, int include_blocked, hrt_path_list *out,
+                           hrt_stats *stats);
+void hrt_path_list_free(hrt_path_list *list);
+
 /* Human-readable description of the last error on this thread ("" if none). */
 const char *hrt_last_error(void);
 
