@@ -55,3 +55,22 @@ def test_bad_material_and_vertex_indices_are_refused(product_lib, scene):
     m.is_[5] = m.num_vertices          # one past the last vertex
     assert _call(product_lib, scene) == -1 and b"vertex index" in product_lib.hrt_last_error()
     m.is_[5] = old
+
+
+def test_path_list_entry_validates_too(product_lib, scene):
+    rx = np.zeros((1, 3), np.float32)
+    pl = abi.PathList()
+    product_lib.hrt_compute_paths_list.restype = C.c_int
+
+    def call(np_=100, nb=2, out=pl, sc=scene):
+        return product_lib.hrt_compute_paths_list(
+            C.byref(sc) if sc is not None else None, rx.ctypes.data_as(V3), rx.ctypes.data_as(V3),
+            rx.ctypes.data_as(V3), rx.ctypes.data_as(V3), C.c_float(3.0), C.c_size_t(1), C.c_size_t(1),
+            C.c_size_t(np_), C.c_size_t(nb), C.c_int(0), C.byref(out) if out is not None else None, None)
+
+    assert call(np_=0) == -1 and b"num_rays" in product_lib.hrt_last_error()
+    assert call(nb=40) == -1 and b"num_bounces" in product_lib.hrt_last_error()
+    assert call(out=None) == -1 and b"NULL" in product_lib.hrt_last_error()
+    assert call(sc=None) == -1 and b"NULL" in product_lib.hrt_last_error()
+    product_lib.hrt_path_list_free(C.byref(pl))      # freeing an empty list is fine
+    product_lib.hrt_path_list_free(None)
