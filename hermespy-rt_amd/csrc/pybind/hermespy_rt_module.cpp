@@ -143,6 +143,68 @@ std::tuple<ChannelInfoPy, ChannelInfoPy> compute_paths_py(
     return {std::move(los.out), std::move(scat.out)};
 }
 
+// compute_paths_list: the same call with the result as ONE list of path records (extension; the
+// reference has no such form).  Returns a dict of numpy arrays, entry n being the record the dense
+// form holds at [rx[n], tx[n], bounce[n] * num_paths + path[n]].
+template <typename T>
+py::array_t<T> copy_out(const T *src, std::vector<size_t> shape)
+{
+    py::array_t<T> a(shape);
+    if (a.size()) std::memcpy(a.mutable_data(), src, sizeof(T) * (size_t)a.size());
+    return a;
+}
+
+py::dict compute_paths_list_py(const std::string &mesh_filepath, farr rx_positions, farr tx_positions,
+                               farr rx_velocities, farr tx_velocities, float carrier_frequency,
+                               unsigned long num_rx, unsigned long num_tx, unsigned long num_paths,
+                               unsigned long num_bounces, bool include_blocked)
+{
+    if (!num_rx || !num_tx || !num_paths || !num_bounces)
+        throw std::invalid_argument("num_rx, num_tx, num_paths, num_bounces must be > 0");
+    const Vec3 *rxp = as_vec3(rx_positions, num_rx, "rx_positions");
+    const Vec3 *txp = as_vec3(tx_positions, num_tx, "tx_positions");
+    const Vec3 *rxv = as_vec3(rx_velocities, num_rx, "rx_velocities");
+    const Vec3 *txv = as_vec3(tx_velocities, num_tx, "tx_velocities");
+    check_scene_file(mesh_filepath);
+    hrt_path_list pl;
+    std::memset(&pl, 0, sizeof pl);
+    int rc;
+    std::string err;
+    {
+        py::gil_scoped_release nogil;
+        Scene scene = scene_load(mesh_filepath.c_str());
+        rc = hrt_compute_paths_list(&scene, rxp, txp, rxv, txv, carrier_frequency, num_rx, num_tx,
+                                    num_paths, num_bounces, include_blocked ? 1 : 0, &pl, nullptr);
+        if (rc != HRT_OK) err = hrt_last_error();
+        free_scene(&scene);
+    }
+    if (rc != HRT_OK)
+        throw std::runtime_error("hermespy_rt.compute_paths_list failed (" + std::to_string(rc) +
+                                 "): " + err);
+    const size_t n = (size_t)pl.num;
+    py::dict d;
+    d["rx"] = copy_out(pl.rx, {n});
+    d["tx"] = copy_out(pl.tx, {n});
+    d["bounce"] = copy_out(pl.bounce, {n});
+    d["path"] = copy_out(pl.path, {n});
+    py::array_t<std::complex<float>> te(std::vector<size_t>{n}), tm(std::vector<size_t>{n});
+    for (size_t i = 0; i < n; ++i) {
+        te.mutable_data()[i] = {pl.a_te_re[i], pl.a_te_im[i]};
+        tm.mutable_data()[i] = {pl.a_tm_re[i], pl.a_tm_im[i]};
+    }
+    d["a_te"] = te;
+    d["a_tm"] = tm;
+    d["tau"] = copy_out(pl.tau, {n});
+    d["direction_rx"] = copy_out(reinterpret_cast<const float *>(pl.direction_rx), {n, 3});
+    d["freq_shift"] = copy_out(pl.freq_shift, {n});
+    d["unblocked"] = copy_out(reinterpret_cast<const bool *>(pl.unblocked), {n});
+    d["mesh"] = copy_out(pl.mesh, {n});
+    d["face"] = copy_out(pl.face, {n});
+    d["los"] = copy_out(pl.los, {(size_t)num_rx, (size_t)num_tx, (size_t)8});
+    hrt_path_list_free(&pl);
+    return d;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(hermespy_rt, m)
@@ -160,5 +222,11 @@ PYBIND11_MODULE(hermespy_rt, m)
           py::arg("mesh_filepath"), py::arg("rx_positions"), py::arg("tx_positions"),
           py::arg("rx_velocities"), py::arg("tx_velocities"), py::arg("carrier_frequency"),
           py::arg("num_rx"), py::arg("num_tx"), py::arg("num_paths"), py::arg("num_bounces"));
+    m.def("compute_paths_list", &compute_paths_list_py,
+          "compute_paths with the result as one list of path records (dict of arrays)",
+          py::arg("mesh_filepath"), py::arg("rx_positions"), py::arg("tx_positions"),
+          py::arg("rx_velocities"), py::arg("tx_velocities"), py::arg("carrier_frequency"),
+          py::arg("num_rx"), py::arg("num_tx"), py::arg("num_paths"), py::arg("num_bounces"),
+          py::arg("include_blocked") = false);
     m.def("version", []() { return std::string(hrt_version()); });
 }

@@ -66,3 +66,32 @@ def test_keyword_names_and_errors(rt):
         rt.compute_paths(**dict(kw, mesh_filepath="/nonexistent.hrt"))
     with pytest.raises(Exception):
         rt.compute_paths(**dict(kw, num_paths=0))
+
+
+def test_compute_paths_list_matches_the_dense_result(rt):
+    """The list extension of the module: every entry equals the dense output at its slot
+    [rx, tx, bounce * num_paths + path]; one entry per non-zero record."""
+    c = K.small(K.C3, 6000)
+    nrx, ntx, npaths, nb = len(c["rx_pos"]), len(c["tx_pos"]), c["num_paths"], c["num_bounces"]
+    args = (c["scene_path"], np.array(c["rx_pos"], np.float32), np.array(c["tx_pos"], np.float32),
+            np.array(c["rx_vel"], np.float32), np.array(c["tx_vel"], np.float32), c["f_ghz"], nrx, ntx,
+            npaths, nb)
+    los, scatter = rt.compute_paths(*args)
+    P = rt.compute_paths_list(*args)
+    n = P["rx"].size
+    slot = (P["rx"].astype(np.int64), P["tx"].astype(np.int64),
+            P["bounce"].astype(np.int64) * npaths + P["path"].astype(np.int64))
+    assert n == int((scatter.directions_rx != 0).any(axis=-1).sum()) and P["unblocked"].all()
+    assert P["a_te"].dtype == np.complex64 and P["path"].dtype == np.uint64
+    assert np.array_equal(P["a_te"], scatter.a_te[slot]) and np.array_equal(P["a_tm"], scatter.a_tm[slot])
+    assert np.array_equal(P["tau"], scatter.tau[slot])
+    assert np.array_equal(P["direction_rx"], scatter.directions_rx[slot])
+    assert np.array_equal(P["freq_shift"], scatter.freq_shift[slot])
+    assert P["los"].shape == (nrx, ntx, 8)
+    clear = P["los"][..., 0].view(np.uint32) == 2
+    assert np.array_equal(P["los"][..., 2][clear], los.tau[..., 0][clear])
+    both = rt.compute_paths_list(*args, include_blocked=True)
+    # blocked records (zeros in the dense form) are listed too, flagged
+    assert both["rx"].size > n and int(both["unblocked"].sum()) == n
+    blk = ~both["unblocked"]
+    assert not both["a_te"][blk].any() and not both["tau"][blk].any()
