@@ -139,12 +139,12 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
             row[3] = e1.x; row[4] = e1.y; row[5] = e1.z;
             row[6] = e2.x; row[7] = e2.y; row[8] = e2.z;
             row[9] = n.x; row[10] = n.y; row[11] = n.z;
-            memcpy(&row[12], &i, 4);
+            memcpy(&row[19], &i, 4);   /* mesh id: last word of the row */
             /* lengths for the packet-culling tolerances, rounded UP (they scale error bounds) */
             {
                 Vec3 e3 = v_sub(e2, e1);
                 Vec3 c = {e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x};
-                float *cr = row + 16;
+                float *cr = row + 15;   /* |e1| |e2| |e2-e1| |e1 x e2| */
                 cr[0] = sqrtf(e1.x * e1.x + e1.y * e1.y + e1.z * e1.z) * 1.000001f;
                 cr[1] = sqrtf(e2.x * e2.x + e2.y * e2.y + e2.z * e2.z) * 1.000001f;
                 cr[2] = sqrtf(e3.x * e3.x + e3.y * e3.y + e3.z * e3.z) * 1.000001f;
@@ -155,9 +155,9 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
                 const double eps = 1.1920928955078125e-07, up = 1.000001;
                 const double Ed = 16.0 * eps * (double)cr[0] * (double)cr[1];
                 const double c2 = 4.0 * eps * (1.0001 * (double)cr[3] + Ed);
-                row[13] = (float)(Ed * up);
-                row[14] = (float)(c2 * up);
-                row[15] = (float)((2.0 * c2 + 2.0 * Ed + 4e-6 * (double)cr[3]) * up);
+                row[12] = (float)(Ed * up);
+                row[13] = (float)(c2 * up);
+                row[14] = (float)((2.0 * c2 + 2.0 * Ed + 4e-6 * (double)cr[3]) * up);
             }
             p->h_tri_mesh[j] = i;
             p->h_tri_face[j] = f;

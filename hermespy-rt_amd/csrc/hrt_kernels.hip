@@ -66,8 +66,8 @@ __device__ __forceinline__ F3 cross3(F3 a, F3 b)
 
 struct Hit { uint32_t tri; float t; };
 
-// One triangle = HRT_ROW float4 (80 bytes): v1.xyz e1.x | e1.yz e2.xy | e2.z n.xyz | mesh - - - |
-// |e1| |e2| |e2-e1| |e1 x e2|.  80 B is deliberate: when the 64 lanes of a wave each read the
+// One triangle = HRT_ROW float4 (80 bytes): v1.xyz e1.x | e1.yz e2.xy | e2.z n.xyz |
+// E_d c_uv c_w |e1| | |e2| |e2-e1| |e1 x e2| mesh.  80 B is deliberate: when the 64 lanes of a wave each read the
 // row of a DIFFERENT triangle (packet culling), the 16-lane groups of a ds_read_b128 start at
 // banks 20*l mod 64 -- 16 distinct multiples of 4 -- so the gather is conflict-free (a 64-byte
 // row gives 4-way conflicts: 76 % of all LDS cycles before the change).
@@ -466,8 +466,13 @@ __device__ __forceinline__ void cone_bounds(const Packet &P, F3 G, float &hp, fl
 // tol_w = 2 (4 eps a_N + E_u + E_v + E_d) + 4e-6 |N| = C.w + 2 (E_u + E_v); the triangle-only
 // parts come from the table (problem.c), the parts proportional to S are formed here.
 __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 q1, float4 q2,
-                                             float4 C, float4 L)
+                                             float4 q3, float4 q4)
 {
+    // the row's last two float4, every word of the first and three of the second are used, so
+    // that the per-lane gathers stay 128-/96-bit LDS reads (split into 32-bit reads at this
+    // row stride they run into 4-way bank conflicts): E_d c_uv c_w |e1| , |e2| |e2-e1| |N| (mesh)
+    const float4 C = make_float4(0.f, q3.x, q3.y, q3.z);
+    const float4 L = make_float4(q3.w, q4.x, q4.y, q4.z);
     constexpr float kE = 16.f * kEps;
     const F3 v1 = {q0.x, q0.y, q0.z};
     const F3 e1 = {q0.w, q1.x, q1.y};
@@ -1037,7 +1042,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             float mat_s = 0.f, mat_alpha = 1.f;
             if (valid) {
                 n = gather3(tri_r, HRT_TRI_FLOATS * 4u, htri, 36u);
-                const uint32_t mesh = ldu(tri_r, 0u, htri * (HRT_TRI_FLOATS * 4u) + 48u);
+                const uint32_t mesh = ldu(tri_r, 0u, htri * (HRT_TRI_FLOATS * 4u) + 76u);
                 const float4 mm = gather4(mesh_r, HRT_MESH_FLOATS * 4u, mesh, 0u);
                 mvel = {mm.x, mm.y, mm.z};
                 const float4 m3 = l_mat[4u * __float_as_uint(mm.w) + 3u];
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                     ntri = ptri;
                     const F3 n = gather3(tri_r, HRT_TRI_FLOATS * 4u, ptri, 36u);
                     nth = incidence_angle(n, d);
-                    const uint32_t mesh = ldu(tri_r, 0u, ptri * (HRT_TRI_FLOATS * 4u) + 48u);
+                    const uint32_t mesh = ldu(tri_r, 0u, ptri * (HRT_TRI_FLOATS * 4u) + 76u);
                     const uint32_t mat =
                         ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
                     float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);

@@ -11,7 +11,7 @@ extern "C" {
 
 #define HRT_NO_HIT 0xFFFFFFFFu
 #define HRT_NUM_MATERIALS 17
-#define HRT_TRI_FLOATS 20  /* v1(3) e1(3) e2(3) n(3) mesh_id(u32) E_d c_uv c_w (culling tolerances) |e1| |e2| |e2-e1| |e1xe2| */
+#define HRT_TRI_FLOATS 20  /* v1(3) e1(3) e2(3) n(3) E_d c_uv c_w (culling tolerances) |e1| |e2| |e2-e1| |e1xe2| mesh_id(u32) */
 #define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */
 #define HRT_MESH_FLOATS 4  /* velocity(3), material_index(u32) */
 #define HRT_BLOCK 256
