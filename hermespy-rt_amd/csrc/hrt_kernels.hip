@@ -575,7 +575,7 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 // (and vice versa), which is what keeps the kernel's register allocation low.
 constexpr uint32_t kMaskRounds = 16;
 
-template <typename TriPtr>
+template <bool MULTI, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, F3 o, F3 d,
                                                   bool valid, uint32_t lane, const Ball &B,
                                                   const bool shadow, F3 apex,
@@ -586,52 +586,60 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
     uint32_t who = HRT_NO_HIT;
     const unsigned long long inval = HRT_BALLOT(!valid);
     if (inval == ~0ull) return {who, best};   // a wave past the end of the live list
-    {
-        const Packet P = packet_bounds(B, d, valid, shadow, apex);
-        HRT_STAT(kind, 0, 1);
-        HRT_STAT(kind, 1, P.usable ? 1 : 0);
-        if (!P.usable) {
-            HRT_STAT(kind, 2, num_tri);
-            for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
-            return {who, best};
+    // The table is walked in blocks of kMaskRounds * 64 = 1024 triangles.  MULTI = false is the
+    // build for scenes of at most one block (the host dispatches on num_tri): the loop below
+    // costs it nothing, while the general build needs 9 more VGPRs (7 waves per SIMD instead of
+    // 8).  The packet description is rebuilt per block (~100 instructions against the ~2000 of
+    // a block's culling) rather than kept alive across the candidate walk.
+    for (uint32_t blk0 = 0; blk0 < (MULTI ? num_tri : 1u); blk0 += kMaskRounds * 64u) {
+        const uint32_t blk1 = MULTI ? min(num_tri, blk0 + kMaskRounds * 64u) : num_tri;
+        {
+            const Packet P = packet_bounds(B, d, valid, shadow, apex);
+            if (blk0 == 0) {
+                HRT_STAT(kind, 0, 1);
+                HRT_STAT(kind, 1, P.usable ? 1 : 0);
+            }
+            if (!P.usable) {
+                HRT_STAT(kind, 2, blk1 - blk0);
+                for (uint32_t j = blk0; j < blk1; ++j) HRT_STAGED_BODY(j)
+                continue;
+            }
+#ifdef HRT_KERNEL_STATS
+            uint32_t ctot = 0;
+#endif
+            for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
+                const uint32_t jl = base + lane;
+                bool cand = false;
+                if (jl < blk1)
+                    cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
+                                         tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 3],
+                                         tri[HRT_ROW * jl + 4]);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+                HRT_STAT(kind, 2, __popcll(m));
+#ifdef HRT_KERNEL_STATS
+                ctot += (uint32_t)__popcll(m);
+#endif
+                if (lane == 0) wmask[r] = m;
+            }
+#ifdef HRT_KERNEL_STATS
+            HRT_STAT(kind, 6, ctot > 24u ? 1 : 0);
+            HRT_STAT(kind, 7, ctot > 24u ? ctot : 0);
+#endif
         }
-#ifdef HRT_KERNEL_STATS
-        uint32_t ctot = 0;
-#endif
-        for (uint32_t base = 0, r = 0; base < num_tri && r < kMaskRounds; base += 64u, ++r) {
-            const uint32_t jl = base + lane;
-            bool cand = false;
-            if (jl < num_tri)
-                cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
-                                     tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 3],
-                                     tri[HRT_ROW * jl + 4]);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
-            HRT_STAT(kind, 2, __popcll(m));
-#ifdef HRT_KERNEL_STATS
-            ctot += (uint32_t)__popcll(m);
-#endif
-            if (lane == 0) wmask[r] = m;
+        for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
+            // written by this wave's lane 0 above, read back by all its lanes: same wave, in order
+            unsigned long long m = wmask[r];
+            // (the builtin returns int: widen through uint32_t or the low word sign-extends)
+            const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+            m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
+            while (m) {   // ascending triangle index: the reference's tie-break order
+                const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                HRT_STAGED_BODY(j)
+            }
         }
-#ifdef HRT_KERNEL_STATS
-        HRT_STAT(kind, 6, ctot > 24u ? 1 : 0);
-        HRT_STAT(kind, 7, ctot > 24u ? ctot : 0);
-#endif
     }
-    for (uint32_t base = 0, r = 0; base < num_tri && r < kMaskRounds; base += 64u, ++r) {
-        // written by this wave's lane 0 above, read back by all its lanes: same wave, in order
-        unsigned long long m = wmask[r];
-        // (the builtin returns int: widen through uint32_t or the low word sign-extends)
-        const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-        const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
-        m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
-        while (m) {   // ascending triangle index: the reference's tie-break order
-            const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
-            m &= m - 1ull;
-            HRT_STAGED_BODY(j)
-        }
-    }
-    // scenes beyond kMaskRounds*64 triangles: the rest is tested without culling
-    for (uint32_t j = kMaskRounds * 64u; j < num_tri; ++j) HRT_STAGED_BODY(j)
     return {who, best};
 }
 
@@ -655,7 +663,8 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F
         if (valid) h = closest_hit_staged(tri, num_tri, o, d);
         return h;
     } else {
-        return closest_hit_packet(tri, num_tri, o, d, valid, lane, B, shadow, apex, wmask, kind);
+        return closest_hit_packet<(VARIANT == 3)>(tri, num_tri, o, d, valid, lane, B, shadow, apex, wmask,
+                                                  kind);
     }
 }
 
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
             if (valid) d = w;
         }
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
-        if constexpr (VARIANT == 2) ball = origin_ball(o, valid);
+        if constexpr (VARIANT >= 2) ball = origin_ball(o, valid);
         const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball, shadow, apex, l_mask,
                                            shadow ? 2 : (first ? 0 : 1));
         if (valid) {
@@ -1437,7 +1446,9 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     // 0 and 1 are kept for A/B timing and as in-library cross-checks (the GPU tests run all).
     static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
     const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
-    const bool in_lds = tri_bytes <= HRT_LDS_TRI_BYTES_MAX;
+    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const bool in_lds = tri_bytes <= lds_max && tri_bytes <= 144u * 1024u;
+    const bool one_block = P->num_tri <= kMaskRounds * 64u;   // packet culling: single-block build
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
                        (HRT_BLOCK / 64u) * kMaskRounds * 8u + 16u;
     hipStream_t st = (hipStream_t)stream;
@@ -1446,11 +1457,12 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
-        else launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
+        else if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
+        else launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
     } else {
         if (variant == 0) launch_trace_t<false, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<false, 1>(P, bounce, nb, lds, st, &err);
-        else launch_trace_t<false, 2>(P, bounce, nb, lds, st, &err);
+        else launch_trace_t<false, 3>(P, bounce, nb, lds, st, &err);   // tables beyond LDS are > 1 block
     }
     if (err != hipSuccess) return (int)err;
     return (int)hipGetLastError();

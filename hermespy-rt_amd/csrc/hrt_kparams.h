@@ -26,7 +26,11 @@ extern "C" {
 #define HRT_SHADE_GRID 16384
 /* triangle tables up to this many bytes are staged in LDS (160 KiB per CU on gfx950, minus
  * the material/endpoint tables); larger scenes read the table through the scalar cache. */
-#define HRT_LDS_TRI_BYTES_MAX (144u * 1024u)
+#define HRT_LDS_TRI_BYTES_MAX (40u * 1024u)   /* larger tables are read from global memory / L2: staged in
+                                              * LDS they would leave fewer than 4 workgroups per CU, and
+                                              * occupancy is worth more than LDS latency (T = 1104: 7.3 ms
+                                              * staged, 2.4 ms from L2); env HRT_LDS_TRI_BYTES_MAX overrides,
+                                              * up to 144 KiB */
 
 typedef struct {
     /* scene (device pointers) */

@@ -72,8 +72,13 @@ print("GENERATED_OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2])
-def test_product_equals_oracle_on_generated_scenes(variant):
+@pytest.mark.parametrize("variant,lds_max", [(0, None), (1, None), (2, None), (2, 147456), (2, 0)])
+def test_product_equals_oracle_on_generated_scenes(variant, lds_max):
+    # lds_max: the triangle table staged in LDS up to the hardware limit (the > 64 KiB dynamic-LDS
+    # path, one workgroup per CU) or never (every scene through the global-memory path); default:
+    # staged up to 40 KiB
     env = dict(os.environ, HRT_TRACE_VARIANT=str(variant))
+    if lds_max is not None:
+        env["HRT_LDS_TRI_BYTES_MAX"] = str(lds_max)
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)
     assert p.returncode == 0 and "GENERATED_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
