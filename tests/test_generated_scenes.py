@@ -28,12 +28,13 @@ def make(tmp, name):
         G.nasty(p)
         return G.cfg(p, [[1, 1, 2.5], [-3, 2, 1.0]], [[0.5, 0.7, 3.0]], 6000, 3, rx_vel=RXV[:2], tx_vel=[[4, 4, 0]])
     n_boxes, tilt, npth, nb = {"t300": (24, False, 6000, 3), "t300_tilted": (24, True, 6000, 3),
-                               "t1104": (91, True, 3000, 2), "t2004_global_table": (166, True, 2000, 2)}[name]
+                               "t1104": (91, True, 3000, 2), "t2004_global_table": (166, True, 2000, 2),
+                               "t6012_six_blocks": (500, True, 1500, 2)}[name]
     G.room_with_clutter(p, n_boxes, seed=len(name), tilt=tilt)
     return G.cfg(p, RX, TX, npth, nb, rx_vel=RXV, tx_vel=[[10, 0, 0]])
 
 
-NAMES = ["t300", "t300_tilted", "t1104", "t2004_global_table", "nasty"]
+NAMES = ["t300", "t300_tilted", "t1104", "t2004_global_table", "t6012_six_blocks", "nasty"]
 
 
 @pytest.mark.parametrize("name", NAMES)
