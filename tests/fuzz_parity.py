@@ -8,8 +8,11 @@ tests/test_gpu_fuzz_slice.py):
                                                  axis-aligned planes, slivers, several meshes, all
                                                  materials, moving meshes
 
+    python tests/fuzz_parity.py big LO HI        150-400 k rays per TX on the bundled scenes
+                                                 (narrow packets, many chunks, stable compaction)
+
 Every case: the product through the drop-in C ABI against the oracle, every output array, bit for
-bit.  Round 1: configs 100-3700 and soups 0-600, 0 mismatches."""
+bit.  Round 1: configs 100-3700, soups 0-650 and big 0-660, 0 mismatches."""
 import os
 import sys
 import tempfile
@@ -52,6 +55,20 @@ def soup_case(seed, tmp):
                  int(rng.integers(1, 7)), f=float(rng.choice([0.7, 3.5, 28.0, 77.0])))
 
 
+def big_case(seed):
+    from tests.test_gpu_random_configs import BOUNDS, SCENES
+    rng = np.random.default_rng(777000 + seed)
+    scene = SCENES[seed % 4]
+    lo, hi = BOUNDS[scene]
+    nrx, ntx = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    c = K.cfg(scene, rng.uniform(lo, hi, (nrx, 3)).tolist(), rng.uniform(lo, hi, (ntx, 3)).tolist(),
+              float(rng.choice([2.4, 3.5, 28.0])), int(rng.integers(150000, 400000)), int(rng.integers(2, 5)))
+    if seed % 2:
+        c["rx_vel"] = rng.uniform(-30, 30, (nrx, 3)).tolist()
+        c["tx_vel"] = rng.uniform(-30, 30, (ntx, 3)).tolist()
+    return c
+
+
 def check(L, c):
     got = abi.run_compute_paths(L, *K.args(c))
     ref = oracle.compute_paths(*K.args(c))
@@ -67,7 +84,7 @@ def main():
     if mode == "configs":
         from tests.test_gpu_random_configs import _case
     for seed in range(lo, hi):
-        c = _case(seed) if mode == "configs" else soup_case(seed, tmp)
+        c = _case(seed) if mode == "configs" else (big_case(seed) if mode == "big" else soup_case(seed, tmp))
         ok, st = check(L, c)
         if not ok:
             bad += 1
