@@ -11,19 +11,25 @@
 //                      reflect), :671-723 (scatter records)
 //   hrt_los_kernel     src/compute_paths.c:515-577
 //
-// Design (MI355X-first, not the reference's loop nest):
-//   * One ray per lane, wave64.  Launch b of the bounce kernel takes the COMPACT live list
-//     produced by launch b-1 (the rays that hit at bounce b-1, with their post-reflection
-//     state), first casts their num_rx shadow rays and writes the scatter records of bounce
-//     b-1 (every lane busy: a live ray always owes its records), then traces bounce b and
-//     appends the survivors to the next live list with a wave ballot + prefix count and ONE
-//     atomic per wave.  Every field of the lists is a separate cap-long array, so a wave
-//     reads and writes 256-byte contiguous runs.
-//   * The triangle table (v1, e1, e2, n, mesh id: 64 B per triangle) is staged once per
-//     workgroup in LDS; the triangle index is wave-uniform, so the inner loop's three
-//     ds_read_b128 are broadcasts (no bank conflicts), and the material table and RX
-//     positions sit next to it.  Scenes larger than the LDS budget fall back to reading the
-//     same table with wave-uniform (scalar-cache) loads.
+// Design (MI355X-first, not the reference's loop nest; DESIGN.md section 5):
+//   * Per launch b two kernels over the COMPACT live list of launch b-1 (the rays that hit at
+//     bounce b-1, with their post-reflection state; at b = 0 the launch set in a coherent order).
+//     hrt_trace_kernel does all intersection work -- per entry the num_rx shadow rays of bounce
+//     b-1 and the ray of bounce b -- and hrt_shade_kernel everything per ray that is not
+//     intersection (scatter records in RX order with the reference's theta carry, Fresnel, free-
+//     space loss, reflection), writing the survivors in order into the next live list (stable
+//     compaction from per-chunk counts: no scan pass, no staging copy).  Every field of the
+//     lists is a separate cap-long array, addressed through buffer descriptors, so a wave reads
+//     and writes 256-byte contiguous runs.
+//   * In the trace kernel a wavefront is a RAY PACKET: wave reductions (DPP, inline asm) bound its
+//     64 origins and directions; the lanes then test 64 TRIANGLES at a time against the packet
+//     (a provably conservative test in numerator space, FMAs allowed: it only bounds) and only
+//     the surviving triangles are walked, every lane testing its own ray with the reference's
+//     exact float sequence behind division-free certain-reject stages.
+//   * The triangle table (80 B rows, conflict-free for per-lane gathers) is staged once per
+//     workgroup in LDS when it is at most 40 KiB, gathered from global memory / L2 otherwise
+//     (occupancy is worth more than LDS latency); the material table and the RX positions sit in
+//     LDS.
 //   * Geometry is IEEE-exact and contraction-free (built with -ffp-contract=off, correctly
 //     rounded division/sqrt, denormals on): hit decisions, hit indices, reflected rays and
 //     delays are BIT-IDENTICAL to the C reference.  The float libm calls of the shading code
