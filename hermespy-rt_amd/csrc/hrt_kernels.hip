@@ -980,12 +980,13 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
 //   (b >= 1) scatter records of bounce b-1 for every RX IN ORDER, carrying theta through the
 //            shadow results (src/compute_paths.c:671-723; quirks Q6, Q7, Q8);
 //   (b < nb) the bounce itself: incidence angle, Fresnel, FSL, delay, reflect (:611-659), and
-//            step 1 of the stable compaction (survivors of the 256-entry chunk to the front
-//            of the chunk's slice of the staging block, count to chunk_cnt).
+//            the stable compaction: every survivor of the 256-entry chunk goes straight to
+//            (survivors of all earlier chunks) + (its rank in the chunk) of the next live list.
 // LDS: [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts][4 u32 wave sums]
 // ===================================================================================
 #ifndef HRT_SHADE_WAVES
-#define HRT_SHADE_WAVES 5   /* 96 VGPRs (8 dwords spilled): 5 waves/SIMD instead of 4, shade -5 % */
+#define HRT_SHADE_WAVES 5   /* an upper bound of 96 VGPRs; the kernel uses ~78: 6 waves/SIMD, no spills
+                             * (7 gains nothing, 8 spills and is 40 % slower) */
 #endif
 __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(const hrt_kparams P,
                                                               const uint32_t b)
