@@ -12,7 +12,7 @@ tests/test_gpu_fuzz_slice.py):
                                                  (narrow packets, many chunks, stable compaction)
 
 Every case: the product through the drop-in C ABI against the oracle, every output array, bit for
-bit.  Round 1: configs 100-3700, soups 0-650 and big 0-660, 0 mismatches."""
+bit.  Round 1: configs 100-12700, soups 0-5650 and big 0-660, 0 mismatches."""
 import os
 import sys
 import tempfile
