@@ -11,8 +11,12 @@ tests/test_gpu_fuzz_slice.py):
     python tests/fuzz_parity.py big LO HI        150-400 k rays per TX on the bundled scenes
                                                  (narrow packets, many chunks, stable compaction)
 
+    python tests/fuzz_parity.py inplane LO HI    endpoints placed exactly in the planes of random
+                                                 scene triangles (inside or far outside them), odd
+                                                 ray counts: the reference's noise regime
+
 Every case: the product through the drop-in C ABI against the oracle, every output array, bit for
-bit.  Round 1: configs 100-12700, soups 0-5650 and big 0-660, 0 mismatches."""
+bit.  Round 1: configs 100-12700, soups 0-5650, big 0-660, inplane 0-3000: 0 mismatches."""
 import os
 import sys
 import tempfile
@@ -69,6 +73,22 @@ def big_case(seed):
     return c
 
 
+def inplane_case(seed):
+    from tests.test_gpu_random_configs import SCENES
+    rng = np.random.default_rng(31000 + seed)
+    scene = SCENES[seed % 4]
+    tris = np.asarray(oracle.flatten(oracle.read_hrt(os.path.join(K.SC, scene)))["tri_vtx"], np.float64).reshape(-1, 3, 3)
+
+    def point():
+        t = tris[int(rng.integers(0, len(tris)))]
+        u, v = rng.uniform(-1.5, 2.5, 2) if rng.random() < 0.5 else rng.uniform(0, 0.5, 2)
+        return (t[0] + u * (t[1] - t[0]) + v * (t[2] - t[0])).astype(np.float32).tolist()
+
+    nrx, ntx = int(rng.integers(1, 5)), int(rng.integers(1, 3))
+    return K.cfg(scene, [point() for _ in range(nrx)], [point() for _ in range(ntx)],
+                 float(rng.choice([2.4, 3.5, 28.0])), 2 * int(rng.integers(200, 3000)) + 1, int(rng.integers(1, 6)))
+
+
 def check(L, c):
     got = abi.run_compute_paths(L, *K.args(c))
     ref = oracle.compute_paths(*K.args(c))
@@ -84,7 +104,8 @@ def main():
     if mode == "configs":
         from tests.test_gpu_random_configs import _case
     for seed in range(lo, hi):
-        c = _case(seed) if mode == "configs" else (big_case(seed) if mode == "big" else soup_case(seed, tmp))
+        c = _case(seed) if mode == "configs" else (big_case(seed) if mode == "big" else
+                                                  (inplane_case(seed) if mode == "inplane" else soup_case(seed, tmp)))
         ok, st = check(L, c)
         if not ok:
             bad += 1
