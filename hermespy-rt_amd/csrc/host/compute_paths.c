@@ -244,7 +244,7 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             m->ns = (Vec3 *)malloc((size_t)(m->num_triangles ? m->num_triangles : 1) * sizeof(Vec3));
             if (!m->ns) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
             for (uint32_t f = 0; f < m->num_triangles; ++f, ++j)
-                memcpy(&m->ns[f], prob->h_tri + (size_t)j * HRT_TRI_FLOATS + 9, sizeof(Vec3));
+                memcpy(&m->ns[f], prob->h_tri + (size_t)prob->accel.newidx[j] * HRT_TRI_FLOATS + 9, sizeof(Vec3));
         }
     }
     st.t_setup_s = hrt_now_s() - t_begin;

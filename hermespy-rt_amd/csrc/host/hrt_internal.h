@@ -30,6 +30,27 @@ typedef struct {
 } hrt_eta;
 void hrt_material_eta(uint32_t material_index, float f_ghz, hrt_eta *out);
 
+/* acceleration structure over the triangle table (accel.c; device side in hrt_kernels.hip) */
+typedef struct hrt_accel {
+    uint32_t num_tri, num_leaf;
+    int big;                     /* inner levels + plane tree present */
+    uint32_t *orig;              /* [T] table row -> index in the reference's (mesh, face) loop order */
+    uint32_t *newidx;            /* [T] inverse */
+    float *leaf;                 /* [num_leaf][HRT_NODE_FLOATS]: c.xyz, R, Lambda */
+    float *tg;                   /* [T][2]: qs, longest edge */
+    uint32_t num_levels;         /* inner levels above the leaves */
+    uint32_t node_count[HRT_ACCEL_MAX_LEVELS];
+    float *node[HRT_ACCEL_MAX_LEVELS];
+    uint32_t pl_num_leaf, pl_levels;
+    uint32_t pl_count[HRT_ACCEL_MAX_LEVELS];
+    float *pl_node[HRT_ACCEL_MAX_LEVELS];   /* [0] = cones of the 64-entry leaves */
+    uint32_t *pl_index;          /* [pl_num_leaf * 64] table rows, HRT_NO_HIT padded */
+    float *pl_rec;               /* [pl_num_leaf * 64][HRT_NODE_FLOATS]: p1.xyz, l, n.xyz, qs */
+} hrt_accel;
+int hrt_accel_order(hrt_accel *a, const float *rows_ref_order, uint32_t T, int reorder);
+int hrt_accel_build(hrt_accel *a, const float *rows_table_order);
+void hrt_accel_free(hrt_accel *a);
+
 struct hrt_problem {
     int device;
     uint32_t num_tri, num_mesh, num_rx, num_tx;
@@ -38,11 +59,13 @@ struct hrt_problem {
     float *h_tri;       /* [num_tri][HRT_TRI_FLOATS] */
     float *h_mesh;      /* [num_mesh][HRT_MESH_FLOATS] */
     float *h_mat;       /* [17][HRT_MAT_FLOATS] */
-    uint32_t *h_tri_mesh, *h_tri_face;
+    uint32_t *h_tri_mesh, *h_tri_face;   /* per table row */
+    hrt_accel accel;
     hrt_eta eta[HRT_NUM_MATERIALS];
     /* one device allocation holding everything */
     void *d_blob;
     const float *d_tri, *d_mesh, *d_mat, *d_rx_pos, *d_tx_pos, *d_rx_vel, *d_tx_vel;
+    hrt_kaccel kaccel;           /* device pointers of the acceleration structure */
 };
 
 /* error plumbing: set the thread's last-error text and return `code` */

@@ -72,6 +72,7 @@ void hrt_problem_destroy(hrt_problem *p)
         hrt_hip_free(p->d_blob);
     }
     free(p->h_tri); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
+    hrt_accel_free(&p->accel);
     free(p);
 }
 
@@ -174,12 +175,60 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
         mt[13] = (float)hrt_materials[m->material_index].s1_alpha;
     }
 
-    /* one device blob: tri | mesh | mat | rx_pos | tx_pos | rx_vel | tx_vel (256-B aligned) */
-    uint64_t sz_tri = round_up((uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4, 256);
-    uint64_t sz_mesh = round_up((uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4, 256);
-    uint64_t sz_mat = round_up(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4, 256);
-    uint64_t sz_rx = round_up((uint64_t)num_rx * 12, 256), sz_tx = round_up((uint64_t)num_tx * 12, 256);
-    uint64_t total = sz_tri + sz_mesh + sz_mat + 2 * sz_rx + 2 * sz_tx;
+    /* ---- acceleration structure: Morton order of the rows (the reference's loop order is kept
+     * in accel.orig for the tie-break), leaf spheres, guard numbers, inner levels, plane tree ---- */
+    {
+        const char *nv = getenv("HRT_NO_REORDER");
+        int rc2 = hrt_accel_order(&p->accel, p->h_tri, (uint32_t)T, !(nv && *nv && *nv != '0'));
+        if (rc2) { hrt_problem_destroy(p); return rc2; }
+        float *rows = (float *)malloc((size_t)(T ? T : 1) * HRT_TRI_FLOATS * sizeof(float));
+        uint32_t *tm = (uint32_t *)malloc((size_t)(T ? T : 1) * 4), *tf = (uint32_t *)malloc((size_t)(T ? T : 1) * 4);
+        if (!rows || !tm || !tf) {
+            free(rows); free(tm); free(tf);
+            hrt_problem_destroy(p);
+            return hrt_fail(HRT_E_NOMEM, "out of host memory");
+        }
+        for (uint32_t k = 0; k < (uint32_t)T; ++k) {
+            const uint32_t o = p->accel.orig[k];
+            memcpy(rows + (size_t)k * HRT_TRI_FLOATS, p->h_tri + (size_t)o * HRT_TRI_FLOATS, HRT_TRI_FLOATS * sizeof(float));
+            tm[k] = p->h_tri_mesh[o];
+            tf[k] = p->h_tri_face[o];
+        }
+        free(p->h_tri); free(p->h_tri_mesh); free(p->h_tri_face);
+        p->h_tri = rows; p->h_tri_mesh = tm; p->h_tri_face = tf;
+        rc2 = hrt_accel_build(&p->accel, p->h_tri);
+        if (rc2) { hrt_problem_destroy(p); return rc2; }
+    }
+
+    /* one device blob (every part 256-B aligned): tri | mesh | mat | rx_pos | tx_pos | rx_vel |
+     * tx_vel | orig | tg | leaf | inner levels | plane-tree levels | plane index | plane records */
+    const hrt_accel *A = &p->accel;
+    const void *src[32];
+    uint64_t len[32], offs[32];
+    int np = 0;
+#define PART(ptr, bytes) (src[np] = (ptr), len[np] = (uint64_t)(bytes), np++)
+    const int i_tri = PART(p->h_tri, (uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4);
+    const int i_mesh = PART(p->h_mesh, (uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4);
+    const int i_mat = PART(p->h_mat, HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4);
+    const int i_rxp = PART(rx_pos, (uint64_t)num_rx * 12);
+    const int i_txp = PART(tx_pos, (uint64_t)num_tx * 12);
+    const int i_rxv = PART(rx_vel, (uint64_t)num_rx * 12);
+    const int i_txv = PART(tx_vel, (uint64_t)num_tx * 12);
+    const int i_orig = PART(A->orig, (uint64_t)(T ? T : 1) * 4);
+    const int i_tg = PART(A->tg, (uint64_t)(T ? T : 1) * 8);
+    const int i_leaf = PART(A->leaf, (uint64_t)(A->num_leaf ? A->num_leaf : 1) * HRT_NODE_FLOATS * 4);
+    int i_node[HRT_ACCEL_MAX_LEVELS], i_pl[HRT_ACCEL_MAX_LEVELS], i_pli = -1, i_plr = -1;
+    for (uint32_t k = 0; k < A->num_levels; ++k)
+        i_node[k] = PART(A->node[k], (uint64_t)A->node_count[k] * HRT_NODE_FLOATS * 4);
+    for (uint32_t k = 0; k < A->pl_levels; ++k)
+        i_pl[k] = PART(A->pl_node[k], (uint64_t)A->pl_count[k] * HRT_NODE_FLOATS * 4);
+    if (A->big) {
+        i_pli = PART(A->pl_index, (uint64_t)A->pl_num_leaf * 64 * 4);
+        i_plr = PART(A->pl_rec, (uint64_t)A->pl_num_leaf * 64 * HRT_NODE_FLOATS * 4);
+    }
+#undef PART
+    uint64_t total = 0;
+    for (int k = 0; k < np; ++k) { offs[k] = total; total += round_up(len[k] ? len[k] : 1, 256); }
     int rc;
     if ((rc = hrt_hip_set_device(device)) != 0) {
         hrt_problem_destroy(p);
@@ -191,22 +240,38 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
         return hrt_fail_hip(rc, "hipMalloc(problem)");
     }
     uint8_t *b = (uint8_t *)p->d_blob;
-    p->d_tri = (const float *)b; b += sz_tri;
-    p->d_mesh = (const float *)b; b += sz_mesh;
-    p->d_mat = (const float *)b; b += sz_mat;
-    p->d_rx_pos = (const float *)b; b += sz_rx;
-    p->d_tx_pos = (const float *)b; b += sz_tx;
-    p->d_rx_vel = (const float *)b; b += sz_rx;
-    p->d_tx_vel = (const float *)b;
-    if ((rc = hrt_hip_h2d((void *)p->d_tri, p->h_tri, (uint64_t)(T ? T : 1) * HRT_TRI_FLOATS * 4)) ||
-        (rc = hrt_hip_h2d((void *)p->d_mesh, p->h_mesh, (uint64_t)p->num_mesh * HRT_MESH_FLOATS * 4)) ||
-        (rc = hrt_hip_h2d((void *)p->d_mat, p->h_mat, HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4)) ||
-        (rc = hrt_hip_h2d((void *)p->d_rx_pos, rx_pos, (uint64_t)num_rx * 12)) ||
-        (rc = hrt_hip_h2d((void *)p->d_tx_pos, tx_pos, (uint64_t)num_tx * 12)) ||
-        (rc = hrt_hip_h2d((void *)p->d_rx_vel, rx_vel, (uint64_t)num_rx * 12)) ||
-        (rc = hrt_hip_h2d((void *)p->d_tx_vel, tx_vel, (uint64_t)num_tx * 12))) {
-        hrt_problem_destroy(p);
-        return hrt_fail_hip(rc, "hipMemcpy(problem)");
+    for (int k = 0; k < np; ++k)
+        if (len[k] && (rc = hrt_hip_h2d(b + offs[k], src[k], len[k]))) {
+            hrt_problem_destroy(p);
+            return hrt_fail_hip(rc, "hipMemcpy(problem)");
+        }
+    p->d_tri = (const float *)(b + offs[i_tri]);
+    p->d_mesh = (const float *)(b + offs[i_mesh]);
+    p->d_mat = (const float *)(b + offs[i_mat]);
+    p->d_rx_pos = (const float *)(b + offs[i_rxp]);
+    p->d_tx_pos = (const float *)(b + offs[i_txp]);
+    p->d_rx_vel = (const float *)(b + offs[i_rxv]);
+    p->d_tx_vel = (const float *)(b + offs[i_txv]);
+    hrt_kaccel *ka = &p->kaccel;
+    memset(ka, 0, sizeof *ka);
+    ka->orig = (const uint32_t *)(b + offs[i_orig]);
+    ka->tg = (const float *)(b + offs[i_tg]);
+    ka->leaf = (const float *)(b + offs[i_leaf]);
+    ka->num_leaf = A->num_leaf;
+    ka->big = A->big ? 1u : 0u;
+    ka->num_levels = A->num_levels;
+    for (uint32_t k = 0; k < A->num_levels; ++k) {
+        ka->node_count[k] = A->node_count[k];
+        ka->node[k] = (const float *)(b + offs[i_node[k]]);
+    }
+    ka->pl_levels = A->pl_levels;
+    for (uint32_t k = 0; k < A->pl_levels; ++k) {
+        ka->pl_count[k] = A->pl_count[k];
+        ka->pl_node[k] = (const float *)(b + offs[i_pl[k]]);
+    }
+    if (A->big) {
+        ka->pl_index = (const uint32_t *)(b + offs[i_pli]);
+        ka->pl_rec = (const float *)(b + offs[i_plr]);
     }
     *out = p;
     return HRT_OK;
@@ -225,8 +290,15 @@ int hrt_problem_eta_table(const hrt_problem *p, float *out)
 
 int hrt_problem_normals(const hrt_problem *p, float *out)
 {
+    /* in the reference's (mesh, face) loop order, whatever the order of the device table */
     for (uint32_t j = 0; j < p->num_tri; ++j)
-        memcpy(out + 3 * (size_t)j, p->h_tri + (size_t)j * HRT_TRI_FLOATS + 9, 12);
+        memcpy(out + 3 * (size_t)j, p->h_tri + (size_t)p->accel.newidx[j] * HRT_TRI_FLOATS + 9, 12);
+    return HRT_OK;
+}
+
+int hrt_problem_tri_order(const hrt_problem *p, uint32_t *orig_of_row)
+{
+    memcpy(orig_of_row, p->accel.orig, (size_t)p->num_tri * 4);
     return HRT_OK;
 }
 
@@ -582,6 +654,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     memset(&K, 0, sizeof K);
     K.tri = p->d_tri; K.mesh = p->d_mesh; K.mat = p->d_mat;
     K.num_tri = p->num_tri; K.num_mesh = p->num_mesh;
+    K.acc = p->kaccel;
     K.rx_pos = p->d_rx_pos; K.tx_pos = p->d_tx_pos; K.rx_vel = p->d_rx_vel; K.tx_vel = p->d_tx_vel;
     K.num_rx = p->num_rx; K.num_tx = p->num_tx;
     K.fsl_mult = p->fsl_mult; K.dop_mult = p->dop_mult;

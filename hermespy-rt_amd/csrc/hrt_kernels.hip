@@ -84,11 +84,16 @@ constexpr uint32_t HRT_ROW = HRT_TRI_FLOATS / 4;
 //
 // Variant 0 ("plain"): the reference's test sequence as written -- three IEEE divisions per
 // triangle that survives the early-outs, per-lane divergent early-outs.
+// The table is in a spatial order (csrc/host/accel.c), so "lowest index wins ties" of the
+// reference's scan becomes: track the lexicographic minimum of (distance, ORIGINAL index) --
+// `orig[j]` is the position of row j in the reference's loop order.  who_o starts at 0, so the
+// tie rule can never fire before a first hit (dist == 1e9f is not a hit in the reference either).
 template <typename TriPtr>
-__device__ __forceinline__ Hit closest_hit_plain(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
+__device__ __forceinline__ Hit closest_hit_plain(TriPtr tri, const uint32_t *__restrict__ orig,
+                                                 uint32_t num_tri, F3 o, F3 d)
 {
     float best = 1e9f;
-    uint32_t who = HRT_NO_HIT;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
     for (uint32_t j = 0; j < num_tri; ++j) {
         const float4 q0 = tri[HRT_ROW * j], q1 = tri[HRT_ROW * j + 1], q2 = tri[HRT_ROW * j + 2];
         const F3 v1 = {q0.x, q0.y, q0.z};
@@ -105,7 +110,9 @@ __device__ __forceinline__ Hit closest_hit_plain(TriPtr tri, uint32_t num_tri, F
         const float w = u + v;
         if (v < -kEps || w > kOnePlusEps) continue;
         const float dist = dot3(e2, q) / det;
-        if (dist > kEps && dist < best) { best = dist; who = j; }
+        if (dist > kEps && (dist < best || (dist == best && orig[j] < who_o))) {
+            best = dist; who = j; who_o = orig[j];
+        }
     }
     return {who, best};
 }
@@ -129,7 +136,7 @@ __device__ __forceinline__ Hit closest_hit_plain(TriPtr tri, uint32_t num_tri, F
 //   R4  u+v > 1+eps     <=  fl(Nu'+Nv') > fl(k3*a)     k3 = 1+2^-19   (given R1..R3 not certain)
 //   R5  dist <= eps     <=  Nt' <  fl(k5*a)            k5 = eps*(1-2^-18)  (all triangles BEHIND
 //                                                       the ray origin fall here)
-//   R6  dist >= best    <=  Nt' >  fl(fl(best*a)*k2)
+//   R6  dist >  best    <=  Nt' >  fl(fl(best*a)*k2)   (strictly: a tie is never rejected here)
 constexpr float kK1 = 1.1920928955078125e-07f * (1.f + 0x1p-18f);
 constexpr float kK2 = 1.f + 0x1p-20f;
 constexpr float kK3 = 1.f + 0x1p-19f;
@@ -151,10 +158,11 @@ __device__ __forceinline__ float xor_sign(float x, uint32_t sign_bit)
 }
 
 template <typename TriPtr>
-__device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, uint32_t num_tri, F3 o, F3 d)
+__device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, const uint32_t *__restrict__ orig,
+                                                  uint32_t num_tri, F3 o, F3 d)
 {
     float best = 1e9f;
-    uint32_t who = HRT_NO_HIT;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
     for (uint32_t j = 0; j < num_tri; ++j) {
         const float4 q0 = tri[HRT_ROW * j], q1 = tri[HRT_ROW * j + 1], q2 = tri[HRT_ROW * j + 2];
         const F3 v1 = {q0.x, q0.y, q0.z};
@@ -186,9 +194,11 @@ __device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, uint32_t num_tri, 
         const float dist = nt / det;
         const bool miss = (det > -kEps && det < kEps) | (u < -kEps) | (u > kOnePlusEps) |
                           (v < -kEps) | (w > kOnePlusEps);
-        const bool take = !rej & !miss & (dist > kEps) & (dist < best);
+        const uint32_t oj = orig[j];
+        const bool take = !rej & !miss & (dist > kEps) & ((dist < best) | ((dist == best) & (oj < who_o)));
         best = take ? dist : best;
         who = take ? j : who;
+        who_o = take ? oj : who_o;
     }
     return {who, best};
 }
@@ -528,7 +538,7 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 // kept as a 64-bit LANE MASK in SGPRs: each ballot of a single comparison is one v_cmp writing an
 // SGPR pair, the ORs and the "every lane rejected?" test are scalar instructions (a ballot of an
 // OR of comparisons costs two extra VALU instructions per stage).  All 64 lanes are active here;
-// `inval` has the bits of the lanes that carry no ray.
+// `inval` has the bits of the lanes that carry no ray.  Ties: lexicographic (distance, orig[J]).
 #define HRT_BALLOT(c) __builtin_amdgcn_ballot_w64(c)
 #define HRT_STAGED_BODY(J)                                                                      \
     {                                                                                           \
@@ -566,9 +576,12 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
                     const bool rej = (rm >> lane) & 1ull;                                       \
                     const bool miss = (det > -kEps && det < kEps) | (u < -kEps) |               \
                                       (u > kOnePlusEps) | (v < -kEps) | (w > kOnePlusEps);      \
-                    const bool take = !rej & !miss & (dist > kEps) & (dist < best);             \
+                    const uint32_t oj = orig[(J)];   /* J is wave-uniform: a scalar load */      \
+                    const bool take = !rej & !miss & (dist > kEps) &                            \
+                                      ((dist < best) | ((dist == best) & (oj < who_o)));        \
                     best = take ? dist : best;                                                  \
                     who = take ? (J) : who;                                                     \
+                    who_o = take ? oj : who_o;                                                  \
                 }                                                                               \
             }                                                                                   \
         }                                                                                       \
@@ -582,14 +595,15 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 constexpr uint32_t kMaskRounds = 16;
 
 template <bool MULTI, typename TriPtr>
-__device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, F3 o, F3 d,
+__device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__restrict__ orig,
+                                                  uint32_t num_tri, F3 o, F3 d,
                                                   bool valid, uint32_t lane, const Ball &B,
                                                   const bool shadow, F3 apex,
                                                   unsigned long long *wmask,
                                                   [[maybe_unused]] int kind)
 {
     float best = 1e9f;
-    uint32_t who = HRT_NO_HIT;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
     const unsigned long long inval = HRT_BALLOT(!valid);
     if (inval == ~0ull) return {who, best};   // a wave past the end of the live list
     // The table is walked in blocks of kMaskRounds * 64 = 1024 triangles.  MULTI = false is the
@@ -649,28 +663,178 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, uint32_t num_tri, 
     return {who, best};
 }
 
+// =====================================================================================
+// Acceleration structure, leaf level (host side csrc/host/accel.c; the proofs
+// are DESIGN.md section 9).  The table is in Morton order, so the 64 rows of a culling round -- a
+// LEAF -- are neighbours, and a round can be dropped WHOLE when the packet passes the leaf's
+// bounding sphere at a distance -- if, and that is the point of the guard below, none of its
+// triangles is "doubly grazing" for the packet: a ray that lies (nearly) IN the plane of a triangle
+// makes all numerators of the reference's test pure rounding noise, and the reference then reports
+// hits on that triangle wherever it is in that plane, however far from the ray.  The per-triangle
+// numerator-space test (packet_culls) keeps those; a distance test alone would drop them.
+//
+// Lemma.  Triangle with unit normal n, area A, longest edge l, p1 its first vertex;
+// ray (o, d), |d| = 1, whose LINE misses the triangle by at least m > 0; S >= |o - p| for every
+// point p of the triangle.  Then two of the three exact edge numerators Nu, Nv, det - Nu - Nv have
+// opposite signs and magnitude at least
+//     Dec = (A / l) max( |d.n| phi,  |n.(o - p1)| min(1/8, phi / (2 S)) ),   phi = m^2 / (2 m + l),
+// and the reference rejects the triangle under both signs of det as soon as Dec exceeds the
+// largest of packet_culls' (doubled) tolerances, which is below 1e-5 l (S + l).  With the safety
+// factor SF = 4 the guard is:  max(...) > qs (S + l),  qs = SF 1e-5 l^2 / A (host, rounded up).
+// Over a packet: |d.n| >= |ax.n| cos(alpha) - sin(alpha); |n.(o - p1)| >= |n.(bc - p1)| - br; the
+// distance from any of the packet's lines to a point c is at least
+// r_perp cos(alpha) - |t| sin(alpha) - ro  (t, r_perp: the coordinates of c - oc along / across ax).
+// A triangle that fails the guard is not lost, it just goes through packet_culls like today.
+// =====================================================================================
+struct LeafFar { float m, phi, kappa, S; };
+
+// lane-parallel over LEAVES: is sphere (c, R) with longest edge lam missed by every line of the
+// packet, and with which constants.  NaN / infinite inputs give m <= 0 or phi = 0: never "safe".
+__device__ __forceinline__ LeafFar leaf_far(const Packet &P, float4 n0, float4 n1)
+{
+    const F3 c = {n0.x, n0.y, n0.z};
+    const float R = n0.w, lam = n1.x;
+    const F3 w = sub3(c, P.oc);
+    const float t = fdot3(w, P.ax);
+    const F3 x = fcross3(w, P.ax);                    // |w x ax| = r_perp, without cancellation
+    const float rp = fast_sqrt(fdot3(x, x));
+    const float w1 = (fabsf(w.x) + fabsf(w.y)) + fabsf(w.z);
+    LeafFar f;
+    // (slack: the packet's cone and radii are already widened; 2e-5 (|w| + R) covers this line)
+    f.m = __builtin_fmaf(rp, P.cosa, -fabsf(t) * P.sina) - P.ro * 1.0001f - R - 2e-5f * (w1 + R);
+    const F3 sb = sub3(c, P.bc);
+    f.S = ((fabsf(sb.x) + fabsf(sb.y)) + fabsf(sb.z)) + R + P.br;          // >= |o - p|, 1-norm
+    const float mm = fmaxf(f.m, 0.f);
+    f.phi = mm * mm * __builtin_amdgcn_rcpf(__builtin_fmaf(2.f, mm, lam)) * 0.9999f;
+    f.kappa = fminf(0.125f, 0.5f * f.phi * __builtin_amdgcn_rcpf(f.S) * 0.9999f);
+    return f;
+}
+
+// lane-parallel over the TRIANGLES of a far leaf: true = provably rejected for every ray of the
+// packet (the guard of the lemma); false = must go through packet_culls.
+__device__ __forceinline__ bool guard_safe(const Packet &P, float4 q0, float4 q2, float2 g, float phi,
+                                           float kappa, float S)
+{
+    const F3 p1 = {q0.x, q0.y, q0.z};
+    const F3 n = {q2.y, q2.z, q2.w};
+    const float dn = fdot3(P.ax, n);
+    const float amin = __builtin_fmaf(fabsf(dn), P.cosa, -P.sina);
+    const F3 sb = sub3(P.bc, p1);
+    const float hc = fdot3(n, sb);
+    const float hmin = fabsf(hc) - P.br * 1.0001f - 2e-6f * ((fabsf(sb.x) + fabsf(sb.y)) + fabsf(sb.z));
+    const float Ti = g.x * (S + g.y);
+    // written so that NaNs (degenerate triangles: qs = inf, n = NaN) compare false: not safe
+    return (amin * phi > Ti) | (hmin * kappa > Ti);
+}
+
+// ALL lanes of the wave must call this (uniform control flow); invalid lanes carry dummies.
+// The table is walked in blocks of kMaskRounds leaves: packet bounds, one round over the block's
+// leaves (far or not), then per leaf either the guard (far) or packet_culls (near, and whatever
+// the guard could not clear), masks parked in LDS, then the candidate walk -- as closest_hit_packet.
+template <bool MULTI, typename TriPtr, typename TgPtr, typename LeafPtr>
+__device__ __forceinline__ Hit closest_hit_tree(TriPtr tri, TgPtr tg, LeafPtr leaf,
+                                                const uint32_t *__restrict__ orig, uint32_t num_tri,
+                                                F3 o, F3 d, bool valid, uint32_t lane, const Ball &B,
+                                                const bool shadow, F3 apex,
+                                                unsigned long long *wmask, float4 *wleaf,
+                                                [[maybe_unused]] int kind)
+{
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
+    const unsigned long long inval = HRT_BALLOT(!valid);
+    if (inval == ~0ull) return {who, best};   // a wave past the end of the live list
+    for (uint32_t blk0 = 0; blk0 < (MULTI ? num_tri : 1u); blk0 += kMaskRounds * 64u) {
+        const uint32_t blk1 = MULTI ? min(num_tri, blk0 + kMaskRounds * 64u) : num_tri;
+        {
+            const Packet P = packet_bounds(B, d, valid, shadow, apex);
+            if (blk0 == 0) {
+                HRT_STAT(kind, 0, 1);
+                HRT_STAT(kind, 1, P.usable ? 1 : 0);
+            }
+            if (!P.usable) {
+                HRT_STAT(kind, 2, blk1 - blk0);
+                for (uint32_t j = blk0; j < blk1; ++j) HRT_STAGED_BODY(j)
+                continue;
+            }
+            // ---- one round over the leaves of this block: lane l looks at leaf blk0/64 + l ----
+            unsigned long long farm;
+            {
+                const uint32_t lf = (blk0 >> 6) + lane;
+                const bool has = lane < kMaskRounds && lf * 64u < blk1;
+                const uint32_t lfc = has ? lf : (blk0 >> 6);
+                const LeafFar f = leaf_far(P, leaf[2u * lfc], leaf[2u * lfc + 1u]);
+                farm = HRT_BALLOT(has && f.m > 0.f);
+                if (lane < kMaskRounds) wleaf[lane] = make_float4(f.phi, f.kappa, f.S, 0.f);
+            }
+#ifdef HRT_KERNEL_STATS
+            uint32_t ctot = 0;
+#endif
+            for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
+                const uint32_t jl = base + lane;
+                bool cand = jl < blk1;
+                if ((farm >> r) & 1ull) {   // wave-uniform
+                    const float4 lc = wleaf[r];   // same address in every lane: a broadcast read
+                    HRT_STAT(kind, 6, 1);
+                    if (cand)
+                        cand = !guard_safe(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 2], tg[jl], lc.x, lc.y, lc.z);
+                    if (HRT_BALLOT(cand) == 0ull) {
+                        HRT_STAT(kind, 7, 1);
+                        if (lane == 0) wmask[r] = 0ull;
+                        continue;
+                    }
+                }
+                if (cand)
+                    cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
+                                         tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 3],
+                                         tri[HRT_ROW * jl + 4]);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+                HRT_STAT(kind, 2, __popcll(m));
+                if (lane == 0) wmask[r] = m;
+            }
+        }
+        for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
+            unsigned long long m = wmask[r];
+            const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+            m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
+            while (m) {
+                const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                HRT_STAGED_BODY(j)
+            }
+        }
+    }
+    return {who, best};
+}
+
 #ifndef HRT_TRACE_VARIANT_DEFAULT
-#define HRT_TRACE_VARIANT_DEFAULT 2
+#define HRT_TRACE_VARIANT_DEFAULT 4
 #endif
 
 // Called by ALL lanes of a wave (uniform control flow); lanes with valid == false carry a dummy
-// ray and their result is meaningless.
-template <int VARIANT, typename TriPtr>
-__device__ __forceinline__ Hit closest_hit(TriPtr tri, uint32_t num_tri, F3 o, F3 d, bool valid,
-                                           uint32_t lane, const Ball &B, const bool shadow,
-                                           F3 apex, unsigned long long *wmask, int kind)
+// ray and their result is meaningless.  VARIANT: 0 plain, 1 staged, 2 / 3 flat packet culling
+// (one block / many), 4 / 5 packet culling behind the leaf spheres + guard (one block / many).
+template <int VARIANT, typename TriPtr, typename TgPtr, typename LeafPtr>
+__device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf,
+                                           const uint32_t *__restrict__ orig, uint32_t num_tri, F3 o,
+                                           F3 d, bool valid, uint32_t lane, const Ball &B,
+                                           const bool shadow, F3 apex, unsigned long long *wmask,
+                                           float4 *wleaf, int kind)
 {
     if constexpr (VARIANT == 0) {
         Hit h = {HRT_NO_HIT, 1e9f};
-        if (valid) h = closest_hit_plain(tri, num_tri, o, d);
+        if (valid) h = closest_hit_plain(tri, orig, num_tri, o, d);
         return h;
     } else if constexpr (VARIANT == 1) {
         Hit h = {HRT_NO_HIT, 1e9f};
-        if (valid) h = closest_hit_staged(tri, num_tri, o, d);
+        if (valid) h = closest_hit_staged(tri, orig, num_tri, o, d);
         return h;
+    } else if constexpr (VARIANT == 2 || VARIANT == 3) {
+        return closest_hit_packet<(VARIANT == 3)>(tri, orig, num_tri, o, d, valid, lane, B, shadow, apex,
+                                                  wmask, kind);
     } else {
-        return closest_hit_packet<(VARIANT == 3)>(tri, num_tri, o, d, valid, lane, B, shadow, apex, wmask,
-                                                  kind);
+        return closest_hit_tree<(VARIANT == 5)>(tri, tg, leaf, orig, num_tri, o, d, valid, lane, B, shadow,
+                                                apex, wmask, wleaf, kind);
     }
 }
 
@@ -900,20 +1064,42 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     const uint32_t T = P.num_tri;
     const uint32_t cap4 = (uint32_t)P.cap * 4u;   // bytes per field array
     const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+    const float2 *g_tg = reinterpret_cast<const float2 *>(P.acc.tg);
+    const float4 *g_leaf = reinterpret_cast<const float4 *>(P.acc.leaf);
+    const uint32_t n_leaf = P.acc.num_leaf;
+    // LDS image (hrt_hip_launch_trace sizes it): [T x 5 float4 rows | T float2 guard pairs, padded to
+    // 16 B | 2 float4 per leaf] (only if staged) [num_rx RX pos][4 waves x 16 u64 masks]
+    // [4 waves x 16 float4 leaf constants][4 u32]
     float4 *l_tri = lds;
-    float4 *l_rx = lds + (TRI_IN_LDS ? HRT_ROW * T : 0u);
+    float2 *l_tg = reinterpret_cast<float2 *>(lds + HRT_ROW * T);
+    float4 *l_leaf = lds + HRT_ROW * T + (T + 1u) / 2u;
+    float4 *l_rx = TRI_IN_LDS ? l_leaf + 2u * n_leaf : lds;
     unsigned long long *l_mask = reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
                                  (tid >> 6) * kMaskRounds;
+    float4 *l_wleaf = reinterpret_cast<float4 *>(reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
+                                                 (HRT_BLOCK / 64u) * kMaskRounds) + (tid >> 6) * kMaskRounds;
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(
-        reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) + (HRT_BLOCK / 64u) * kMaskRounds);
-    if (TRI_IN_LDS)
+        reinterpret_cast<float4 *>(reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
+                                   (HRT_BLOCK / 64u) * kMaskRounds) + (HRT_BLOCK / 64u) * kMaskRounds);
+    if (TRI_IN_LDS) {
         for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
+        for (uint32_t k = tid; k < T; k += HRT_BLOCK) l_tg[k] = g_tg[k];
+        for (uint32_t k = tid; k < 2u * n_leaf; k += HRT_BLOCK) l_leaf[k] = g_leaf[k];
+    }
     for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
         l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
     __syncthreads();
     auto tri = [&]() {
         if constexpr (TRI_IN_LDS) return (const float4 *)l_tri;
         else return g_tri;
+    }();
+    auto tg = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float2 *)l_tg;
+        else return g_tg;
+    }();
+    auto leaf = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float4 *)l_leaf;
+        else return g_leaf;
     }();
     const uint32_t lane = tid & 63u;
 
@@ -948,8 +1134,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
         }
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
         if constexpr (VARIANT >= 2) ball = origin_ball(o, valid);
-        const Hit h = closest_hit<VARIANT>(tri, T, o, d, valid, lane, ball, shadow, apex, l_mask,
-                                           shadow ? 2 : (first ? 0 : 1));
+        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc.orig, T, o, d, valid, lane, ball, shadow,
+                                           apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
         if (valid) {
             stu(res_blk(P, k), 0u, i4, h.tri);
             stf(res_blk(P, k), cap4, i4, h.t);
@@ -1448,28 +1634,36 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
-    // HRT_TRACE_VARIANT: 2 = packet culling + staged tests (default), 1 = staged tests over all
-    // triangles, 0 = the reference's plain sequence.  All three give bit-identical results;
-    // 0 and 1 are kept for A/B timing and as in-library cross-checks (the GPU tests run all).
+    // HRT_TRACE_VARIANT: 4 = packet culling behind the leaf spheres + guard (default), 2 = flat
+    // packet culling, 1 = staged tests over all triangles, 0 = the reference's plain sequence.  All
+    // give bit-identical results; 0-2 are kept for A/B timing and as in-library cross-checks (the
+    // GPU tests run all).
     static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
-    const uint64_t tri_bytes = (uint64_t)P->num_tri * HRT_TRI_FLOATS * 4u;
+    const uint64_t T = P->num_tri;
+    // staged image: rows + guard pairs (padded to 16 B) + leaf records
+    const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
+                               (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
     static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
-    const bool in_lds = tri_bytes <= lds_max && tri_bytes <= 144u * 1024u;
+    const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;   // packet culling: single-block build
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * 8u + 16u;
+                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 16u) + 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
     if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
-        else if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
-        else launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
+        else if (variant == 2 || variant == 3) {
+            if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
+            else launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
+        } else if (one_block) launch_trace_t<true, 4>(P, bounce, nb, lds, st, &err);
+        else launch_trace_t<true, 5>(P, bounce, nb, lds, st, &err);
     } else {
         if (variant == 0) launch_trace_t<false, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<false, 1>(P, bounce, nb, lds, st, &err);
-        else launch_trace_t<false, 3>(P, bounce, nb, lds, st, &err);   // tables beyond LDS are > 1 block
+        else if (variant == 2 || variant == 3) launch_trace_t<false, 3>(P, bounce, nb, lds, st, &err);
+        else launch_trace_t<false, 5>(P, bounce, nb, lds, st, &err);   // tables beyond LDS are > 1 block
     }
     if (err != hipSuccess) return (int)err;
     return (int)hipGetLastError();

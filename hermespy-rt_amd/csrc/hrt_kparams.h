@@ -32,12 +32,37 @@ extern "C" {
                                               * staged, 2.4 ms from L2); env HRT_LDS_TRI_BYTES_MAX overrides,
                                               * up to 144 KiB */
 
+/* ---- acceleration structure (host: csrc/host/accel.c; proofs: DESIGN.md section 9) ---- */
+#define HRT_NODE_FLOATS 8           /* a sphere node: c.xyz, R, Lambda, -, -, -; a cone node: nu.xyz,
+                                     * sin(beta+g), cos(beta+g); a guard record: p1.xyz, l, n.xyz, qs */
+#define HRT_ACCEL_MAX_LEVELS 3      /* 64-ary levels above the leaves: up to 64^4 = 16.7 M triangles */
+#define HRT_ACCEL_BIG 4096u         /* tables with more triangles get inner levels + the plane tree */
+#define HRT_GUARD_SF 4.0            /* safety factor on the reference's noise bound 1e-5 l (S + l) */
+#define HRT_GUARD_MU 0.0625         /* big tables: a sphere is "far" when missed by mu * S and Lambda */
+
+typedef struct {
+    const uint32_t *orig;           /* [T] table row -> index in the reference's loop order */
+    const float *tg;                /* [T][2]: qs, longest edge */
+    const float *leaf;              /* [num_leaf][HRT_NODE_FLOATS] */
+    uint32_t num_leaf;
+    uint32_t big;                   /* inner levels + plane tree present */
+    uint32_t num_levels;
+    uint32_t node_count[HRT_ACCEL_MAX_LEVELS];
+    const float *node[HRT_ACCEL_MAX_LEVELS];
+    uint32_t pl_levels;
+    uint32_t pl_count[HRT_ACCEL_MAX_LEVELS];
+    const float *pl_node[HRT_ACCEL_MAX_LEVELS];
+    const uint32_t *pl_index;
+    const float *pl_rec;
+} hrt_kaccel;
+
 typedef struct {
     /* scene (device pointers) */
     const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
     const float *mesh;    /* [num_mesh][HRT_MESH_FLOATS] */
     const float *mat;     /* [17][HRT_MAT_FLOATS] */
     uint32_t num_tri, num_mesh;
+    hrt_kaccel acc;
     /* endpoints (device pointers, [n][3]) */
     const float *rx_pos, *tx_pos, *rx_vel, *tx_vel;
     uint32_t num_rx, num_tx;

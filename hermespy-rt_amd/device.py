@@ -50,6 +50,12 @@ class Tracer:
         finally:
             abi.free_scene(scene)
         self.num_tri = int(self.L.hrt_problem_num_triangles(self.problem))
+        # rows of the device table are in a spatial order (acceleration structure); tri_order[row]
+        # = the flat index the reference's (mesh, face) scan gives that triangle
+        self.tri_order = np.empty(max(self.num_tri, 1), np.uint32)
+        _lib.check(self.L.hrt_problem_tri_order(self.problem,
+                                                self.tri_order.ctypes.data_as(C.POINTER(C.c_uint32))),
+                   "hrt_problem_tri_order")
 
         self.shard = _lib.Shard(self.num_paths, rank, world, chunk, self.nb)
         self.num_local = int(self.L.hrt_shard_num_local(C.byref(self.shard)))
@@ -354,7 +360,7 @@ class Tracer:
             h = {k: v.cpu().numpy() for k, v in self.hits(b, n).items()}
             ray = h["ray"].astype(np.int64) & 0xFFFFFFFF
             tx, p = self.global_path(ray)
-            hit_tri[b, tx, p] = h["tri"].view(np.uint32)
+            hit_tri[b, tx, p] = self.tri_order[h["tri"].view(np.uint32)]   # reference's flat index
             hit_theta[b, tx, p] = h["theta"]
             fs0[b, tx, p] = h["fs0"]
             for k, name in enumerate(("ox", "oy", "oz", "dx", "dy", "dz", "a_te_re", "a_te_im",

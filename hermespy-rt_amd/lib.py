@@ -16,7 +16,7 @@ EXPORTED = (
     "hrt_path_list_free", "hrt_last_error",
     "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
-    "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_shard_num_local",
+    "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_problem_tri_order", "hrt_shard_num_local",
     "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_layout_query", "hrt_trace",
     "hrt_work_from_counts", "hrt_timer_create", "hrt_timer_destroy", "hrt_trace_timed",
     "hrt_trace_flags",
@@ -106,6 +106,7 @@ def load():
     L.hrt_problem_eta_table.argtypes = [vp, f32p]
     L.hrt_problem_normals.argtypes = [vp, f32p]
     L.hrt_problem_tri_ids.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.hrt_problem_tri_order.argtypes = [vp, C.POINTER(u32)]
     L.hrt_shard_num_local.argtypes = [C.POINTER(Shard)]
     L.hrt_shard_num_local.restype = u64
     L.hrt_shard_global_path.argtypes = [C.POINTER(Shard), u64]

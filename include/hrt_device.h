@@ -41,11 +41,17 @@ uint32_t hrt_problem_num_tx(const hrt_problem *p);
 int hrt_problem_device(const hrt_problem *p);
 
 /* Host copies of what was uploaded (for tests): eta table [17][12] in the reference's
- * MaterialPrecomputed field order (src/compute_paths.c:125-132); normals [T][3]; for flat
- * triangle j its (mesh, face) pair. */
+ * MaterialPrecomputed field order (src/compute_paths.c:125-132); normals [T][3]; for row j of
+ * the device table its (mesh, face) pair. */
 int hrt_problem_eta_table(const hrt_problem *p, float *out17x12);
-int hrt_problem_normals(const hrt_problem *p, float *outTx3);
+int hrt_problem_normals(const hrt_problem *p, float *outTx3);   /* in the reference's loop order */
 int hrt_problem_tri_ids(const hrt_problem *p, uint32_t *mesh_out, uint32_t *face_out);
+/* The device table is kept in a spatial (Morton) order for the acceleration structure
+ * (csrc/host/accel.c); HRT_HIT_TRI values are rows of THAT table.  out[j] = position of row j in
+ * the reference's (mesh, face) loop order (src/compute_paths.c:253-254), i.e. the flat index the
+ * reference's scan would give the same triangle.  Environment: HRT_NO_REORDER=1 keeps the
+ * reference's order (the identity here). */
+int hrt_problem_tri_order(const hrt_problem *p, uint32_t *orig_of_row);
 
 /* A shard of the launch set.  The N = num_paths launch directions of every TX are cut into
  * granules of `chunk` consecutive path indices dealt round-robin to `count` shards, so every

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time per step of the hot path on generated rooms full of tilted boxes (tests/scenes_gen.py) as a
+function of the triangle count T, for one HRT_TRACE_VARIANT (latched per process):
+
+    HRT_TRACE_VARIANT=2 python profiles/accel_scaling.py 24 91 166 500 1000 4000 8333
+
+1 M rays, 3 RX, 2 bounces (the workload of DESIGN.md section 9).  Prints one JSON line per scene."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from hermespy_rt_amd.device import Tracer  # noqa: E402
+from tests import scenes_gen as G  # noqa: E402
+
+RX = [[5, 3, 1.5], [-8, -4, 2.0], [12, 9, 8.0]]
+TX = [[-10, 5, 6.0]]
+
+
+def main():
+    tmp = tempfile.mkdtemp()
+    rays = int(os.environ.get("HRT_SCALING_RAYS", "1000000"))
+    for nb in [int(x) for x in sys.argv[1:]]:
+        p = os.path.join(tmp, "room_%d.hrt" % nb)
+        T = G.room_with_clutter(p, nb, seed=7, tilt=True, scale=max(1.0, (nb / 500.0) ** (1.0 / 3.0)))
+        t0 = time.time()
+        tr = Tracer(p, RX, TX, [[0, 0, 0]] * 3, [[0, 0, 0]], 3.5, rays, 2)
+        t_build = time.time() - t0
+        for _ in range(2):
+            tr.trace()
+        torch.cuda.synchronize()
+        n = 5 if T < 20000 else 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.trace()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        c = tr.counts()
+        w = tr.work(c)
+        print(json.dumps(dict(variant=os.environ.get("HRT_TRACE_VARIANT", "default"), boxes=nb, T=T,
+                              ms_per_step=ms, live=w["live"], tests_per_s=w["tests"] / ms * 1e3,
+                              setup_s=t_build)), flush=True)
+        tr.close()
+
+
+if __name__ == "__main__":
+    main()

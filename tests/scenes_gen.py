@@ -32,15 +32,20 @@ def _box(center, size):
     return v, f
 
 
-def room_with_clutter(path, n_boxes, seed=1, moving=True, tilt=False):
+def room_with_clutter(path, n_boxes, seed=1, moving=True, tilt=False, scale=1.0, max_meshes=900):
     """A 40 x 30 x 12 m room (inward walls = one box mesh) with n_boxes random boxes inside:
-    12 * (n_boxes + 1) triangles.  Materials cycle through all 17; odd meshes move."""
+    12 * (n_boxes + 1) triangles.  Materials cycle through all 17; odd meshes move.
+    `scale` stretches the room (not the boxes): scale = (n_boxes / 500) ** (1/3) keeps the clutter
+    density of the 500-box room.  The file format allows 1000 meshes (src/scene.c:54 of the
+    reference): beyond max_meshes boxes, consecutive boxes share a mesh."""
     rng = np.random.default_rng(seed)
     meshes = []
-    v, f = _box([0, 0, 6], [40, 30, 12])
+    v, f = _box([0, 0, 6 * scale], [40 * scale, 30 * scale, 12 * scale])
     meshes.append(dict(vs=v, idx=f, material_index=1, velocity=[0, 0, 0]))
+    per = max(1, -(-n_boxes // max_meshes))
+    cur = None
     for i in range(n_boxes):
-        c = rng.uniform([-18, -13, 0.5], [18, 13, 10])
+        c = rng.uniform([-18 * scale, -13 * scale, 0.5], [18 * scale, 13 * scale, 12 * scale - 2])
         sz = rng.uniform(0.3, 2.5, 3)
         v, f = _box(c, sz)
         if tilt:   # rotate about z and x so normals are not axis aligned
@@ -48,8 +53,14 @@ def room_with_clutter(path, n_boxes, seed=1, moving=True, tilt=False):
             Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
             Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
             v = ((v - c) @ (Rz @ Rx).T + c).astype(np.float32)
-        vel = rng.uniform(-30, 30, 3) if (moving and i % 2) else np.zeros(3)
-        meshes.append(dict(vs=v, idx=f, material_index=i % 17, velocity=vel))
+        if i % per == 0:
+            k = i // per
+            vel = rng.uniform(-30, 30, 3) if (moving and k % 2) else np.zeros(3)
+            cur = dict(vs=v, idx=f, material_index=k % 17, velocity=vel)
+            meshes.append(cur)
+        else:
+            cur["idx"] = np.concatenate([cur["idx"], f + len(cur["vs"])]).astype(np.uint32)
+            cur["vs"] = np.concatenate([cur["vs"], v]).astype(np.float32)
     write_hrt(path, meshes)
     return 12 * (n_boxes + 1)
 
