@@ -320,9 +320,9 @@ def main():
     try:
         import ctypes
         from hermespy_rt_amd import lib as _l2
-        arr = (ctypes.c_uint64 * 24)()
+        arr = (ctypes.c_uint64 * 48)()
         if _l2.load().hrt_debug_kernel_stats(local_rank, arr, 0) == 0 and any(arr):
-            kstats = [[int(arr[k * 8 + j]) for j in range(8)] for k in range(3)]
+            kstats = [[int(arr[k * 16 + j]) for j in range(8)] for k in range(3)]
     except Exception:
         pass
     if rank == 0:

@@ -3,9 +3,9 @@
  *
  * What is built here, on the host, once per problem (DESIGN.md section 9 has the proofs):
  *
- *   1. ORDER.  The triangle table is put into Morton order of the triangle centroids, so that
- *      64 consecutive rows -- one culling round of the trace kernel, a LEAF -- are neighbours in
- *      space.  The reference resolves equal-distance ties by its loop order (lowest (mesh, face)
+ *   1. ORDER.  The triangle table is put into a balanced k-d order of the triangle centroids, so
+ *      that 64 consecutive rows -- one culling round of the trace kernel, a LEAF -- are neighbours
+ *      in space, and so are the 64 leaves of every node above.  The reference resolves equal-distance ties by its loop order (lowest (mesh, face)
  *      wins, src/compute_paths.c:253-275); the kernels keep that by tracking the lexicographic
  *      minimum of (distance, original index), for which `orig` (new -> original) is uploaded.
  *   2. LEAVES.  Per leaf a bounding sphere (c, R) of its triangles and Lambda, its longest edge;
@@ -21,6 +21,7 @@
  * Everything is computed in double and rounded to the conservative side.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,16 +31,6 @@
 
 static double dmax(double a, double b) { return a > b ? a : b; }
 
-/* 10 bits -> every third bit */
-static uint32_t spread3(uint32_t v)
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
 static uint32_t spread2(uint32_t v)   /* 15 bits -> every second bit */
 {
     v &= 0x7fffu;
@@ -76,46 +67,83 @@ void hrt_accel_free(hrt_accel *a)
     memset(a, 0, sizeof *a);
 }
 
-/* Morton order of the centroids.  rows: [T][HRT_TRI_FLOATS] in the reference's (mesh, face) order.
- * Fills a->orig / a->newidx.  `reorder` == 0 keeps the identity. */
+/* Spatial order of the rows: a balanced k-d ordering of the triangle centroids -- the index range
+ * is cut at the median of its longest axis, recursively, the cut rounded to a multiple of the
+ * largest power of 64 below the range (so that leaves of 64 rows, and the 64-leaf groups of every
+ * level above, are each one compact cell) -- Morton order proved too loose: 64 consecutive codes
+ * often straddle a jump of the curve.  Triangles with a non-finite centroid go last.
+ * rows: [T][HRT_TRI_FLOATS] in the reference's (mesh, face) order.  Fills a->orig / a->newidx.
+ * `reorder` == 0 keeps the identity. */
+typedef struct { float c[3]; uint32_t idx; } cent;
+static int g_axis;
+static int cent_cmp(const void *a, const void *b)
+{
+    const cent *x = (const cent *)a, *y = (const cent *)b;
+    if (x->c[g_axis] != y->c[g_axis]) return x->c[g_axis] < y->c[g_axis] ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+static void kd_order(cent *v, uint32_t n)
+{
+    while (n > 64u) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                if (v[i].c[k] < lo[k]) lo[k] = v[i].c[k];
+                if (v[i].c[k] > hi[k]) hi[k] = v[i].c[k];
+            }
+        int ax = 0;
+        if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1;
+        if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+        g_axis = ax;                       /* (called under the problem-creation lock: one builder at a time) */
+        qsort(v, n, sizeof(cent), cent_cmp);
+        uint32_t unit = 64u;
+        while ((uint64_t)unit * 64u < n) unit *= 64u;
+        uint32_t r = unit * (uint32_t)((n + unit) / (2u * unit));   /* ~ n / 2, a multiple of unit */
+        if (r == 0) r = unit;
+        if (r >= n) r = n - (n % unit ? n % unit : unit);
+        if (r == 0 || r >= n) return;
+        kd_order(v, r);                    /* recurse on the left, loop on the right */
+        v += r;
+        n -= r;
+    }
+}
+
+static pthread_mutex_t g_kd_lock = PTHREAD_MUTEX_INITIALIZER;
+
 int hrt_accel_order(hrt_accel *a, const float *rows, uint32_t T, int reorder)
 {
     memset(a, 0, sizeof *a);
     a->num_tri = T;
     a->orig = (uint32_t *)malloc((size_t)(T ? T : 1) * 4);
     a->newidx = (uint32_t *)malloc((size_t)(T ? T : 1) * 4);
-    keyed *ks = (keyed *)malloc((size_t)(T ? T : 1) * sizeof(keyed));
-    if (!a->orig || !a->newidx || !ks) { free(ks); return hrt_fail(HRT_E_NOMEM, "out of host memory"); }
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    cent *cs = (cent *)malloc((size_t)(T ? T : 1) * sizeof(cent));
+    if (!a->orig || !a->newidx || !cs) { free(cs); return hrt_fail(HRT_E_NOMEM, "out of host memory"); }
+    uint32_t nf = 0, nb = T;               /* finite centroids from the front, the others from the back */
     for (uint32_t j = 0; j < T; ++j) {
         const float *r = rows + (size_t)j * HRT_TRI_FLOATS;
-        for (int c = 0; c < 3; ++c) {
-            const double g = (double)r[c] + ((double)r[3 + c] + (double)r[6 + c]) / 3.0;
-            if (isfinite(g)) { if (g < lo[c]) lo[c] = g; if (g > hi[c]) hi[c] = g; }
-        }
-    }
-    for (uint32_t j = 0; j < T; ++j) {
-        const float *r = rows + (size_t)j * HRT_TRI_FLOATS;
-        uint32_t key = 0;
+        cent c;
         int ok = 1;
-        for (int c = 0; c < 3 && ok; ++c) {
-            const double g = (double)r[c] + ((double)r[3 + c] + (double)r[6 + c]) / 3.0;
-            if (!isfinite(g)) { ok = 0; break; }
-            const double ext = hi[c] - lo[c];
-            double u = ext > 0 ? (g - lo[c]) / ext : 0.0;
-            if (!(u >= 0)) u = 0;
-            if (u > 1) u = 1;
-            key |= spread3((uint32_t)(u * 1023.0)) << c;
+        for (int k = 0; k < 3; ++k) {
+            const double g = (double)r[k] + ((double)r[3 + k] + (double)r[6 + k]) / 3.0;
+            c.c[k] = (float)g;
+            if (!isfinite(c.c[k])) ok = 0;
         }
-        ks[j].key = (ok && reorder) ? key : (reorder ? 0xffffffffu : 0u);   /* non-finite: last */
-        ks[j].idx = j;
+        c.idx = j;
+        if (ok || !reorder) cs[nf++] = c;
+        else cs[--nb] = c;
     }
-    if (reorder) qsort(ks, T, sizeof(keyed), keyed_cmp);
+    if (reorder) {
+        pthread_mutex_lock(&g_kd_lock);
+        kd_order(cs, nf);
+        pthread_mutex_unlock(&g_kd_lock);
+        /* the non-finite ones: in index order behind the rest */
+        for (uint32_t i = nb, k = T; i < k && i + 1 < k; ++i, --k) { const cent t = cs[i]; cs[i] = cs[k - 1]; cs[k - 1] = t; }
+    }
     for (uint32_t j = 0; j < T; ++j) {
-        a->orig[j] = ks[j].idx;
-        a->newidx[ks[j].idx] = j;
+        a->orig[j] = cs[j].idx;
+        a->newidx[cs[j].idx] = j;
     }
-    free(ks);
+    free(cs);
     return HRT_OK;
 }
 
@@ -215,9 +243,41 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
     }
     free(cs); free(rs);
     {
-        const char *v = getenv("HRT_ACCEL_BIG");   /* tables with MORE triangles get inner levels + plane tree */
+        /* Inner levels + plane tree pay when a leaf is small against the scene (a packet then passes
+         * most leaves at a distance): tables of more than HRT_ACCEL_BIG triangles whose median leaf
+         * radius is below HRT_ACCEL_SPARSE of the scene's.  In a dense scene (a room full of clutter,
+         * every leaf near every ray) the per-triangle culling of the flat walk is the better tool.
+         * Environment: HRT_ACCEL_BIG=n replaces the triangle threshold (0: always) and drops the
+         * sparseness condition; HRT_ACCEL_SPARSE=x replaces the ratio. */
+        const char *v = getenv("HRT_ACCEL_BIG"), *sp = getenv("HRT_ACCEL_SPARSE");
         const unsigned long long thr = (v && *v) ? strtoull(v, NULL, 10) : HRT_ACCEL_BIG;
         a->big = (unsigned long long)T > thr;
+        if (a->big && !(v && *v)) {
+            const double ratio = (sp && *sp) ? atof(sp) : HRT_ACCEL_SPARSE;
+            float *rad = (float *)malloc((size_t)nl * sizeof(float));
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t n = 0;
+            if (!rad) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+            for (uint32_t b = 0; b < nl; ++b) {
+                const float *L = a->leaf + (size_t)b * HRT_NODE_FLOATS;
+                if (!isfinite(L[3])) continue;
+                rad[n++] = L[3];
+                for (int k = 0; k < 3; ++k) {
+                    if (L[k] < lo[k]) lo[k] = L[k];
+                    if (L[k] > hi[k]) hi[k] = L[k];
+                }
+            }
+            if (n) {
+                /* median by partial selection: nl is small (T / 64) */
+                for (uint32_t i = 0; i <= n / 2; ++i)
+                    for (uint32_t j = i + 1; j < n; ++j)
+                        if (rad[j] < rad[i]) { const float t = rad[i]; rad[i] = rad[j]; rad[j] = t; }
+                const double ext = 0.5 * sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
+                                              (hi[2] - lo[2]) * (hi[2] - lo[2]));
+                a->big = (double)rad[n / 2] < ratio * ext;
+            } else a->big = 0;
+            free(rad);
+        }
     }
     if (!a->big) return HRT_OK;
 
@@ -290,7 +350,7 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
         }
         /* cone levels: level 0 = leaves of 64 entries, level k = 64 nodes of level k-1.  Node =
          * axis nu, then sin and cos of (beta + g): beta the largest angle between nu and a member
-         * normal (sign dropped), g = asin(Gamma), Gamma = (6 / mu) max qs the direction margin the
+         * normal (sign dropped), g = asin(Gamma), Gamma = (12 / mu) max qs the direction margin the
          * members need.  (2, 0) = "always visit". */
         uint32_t span = 64u, k = 0, count = pnl;
         for (;;) {
@@ -306,7 +366,7 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
                     if (!have) { memcpy(first, cn[j], sizeof first); have = 1; }
                     const double sg = (cn[j][0] * first[0] + cn[j][1] * first[1] + cn[j][2] * first[2]) < 0 ? -1.0 : 1.0;
                     for (int c = 0; c < 3; ++c) s[c] += sg * cn[j][c];
-                    gam = dmax(gam, (6.0 / HRT_GUARD_MU) * (double)a->tg[2 * (size_t)j]);
+                    gam = dmax(gam, (12.0 / HRT_GUARD_MU) * (double)a->tg[2 * (size_t)j]);
                 }
                 float *N = lev + (size_t)nidx * HRT_NODE_FLOATS;
                 const double sl = sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);

@@ -259,6 +259,7 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
     ka->leaf = (const float *)(b + offs[i_leaf]);
     ka->num_leaf = A->num_leaf;
     ka->big = A->big ? 1u : 0u;
+    { const char *dv = getenv("HRT_ACCEL_DEBUG"); ka->dbg = (dv && *dv) ? (uint32_t)atoi(dv) : 0u; }
     ka->num_levels = A->num_levels;
     for (uint32_t k = 0; k < A->num_levels; ++k) {
         ka->node_count[k] = A->node_count[k];
@@ -532,7 +533,9 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     memset(L, 0, sizeof *L);
     L->cap = cap;
     uint64_t off = 0;
-    L->off_counts = off; off += round_up((nb + 2) * 4, 256);
+    /* counts[nb + 2], then (from byte 256) one work-unit counter per launch for the trace kernel's
+     * dynamic unit distribution on big tables; zeroed together at the start of every trace */
+    L->off_counts = off; off += 512;
     /* survivor counts per super-chunk (HRT_SUPER_CHUNKS chunks of 256 entries) and bounce: directly behind
      * the counts, zeroed with them at the start of every trace */
     L->num_super = cap / HRT_BLOCK / HRT_SUPER_CHUNKS + 1;
@@ -784,12 +787,11 @@ int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t 
 }
 
 /* Diagnostic counters of the packet-culling loop (all zero unless built with `make STATS=1`):
- * out[kind][8], kind 0 = primary traces of launch 0, 1 = primary traces of later launches,
- * 2 = shadow traces; columns: wave-traces, usable packets, candidate triangles, staged bodies
- * reaching stage 2, stage 3, the exact divisions. */
-int hrt_debug_kernel_stats(int device, uint64_t *out24, int reset)
+ * out[kind][16], kind 0 = primary traces of launch 0, 1 = primary traces of later launches,
+ * 2 = shadow traces; columns: see include/hrt_device.h. */
+int hrt_debug_kernel_stats(int device, uint64_t *out48, int reset)
 {
     HRT_HIP(hrt_hip_set_device(device), "hipSetDevice");
-    HRT_HIP(hrt_hip_read_stats((unsigned long long *)out24, reset), "hrt_hip_read_stats");
+    HRT_HIP(hrt_hip_read_stats((unsigned long long *)out48, reset), "hrt_hip_read_stats");
     return HRT_OK;
 }

@@ -230,7 +230,7 @@ __device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, const uint32_t *__
 // (0 primary of launch 0, 1 primary of later launches, 2 shadow): wave-traces, usable packets,
 // candidate triangles, staged bodies that reached stage 2 / 3 / the exact divisions.
 #ifdef HRT_KERNEL_STATS
-__device__ unsigned long long g_stats[3][8];
+__device__ unsigned long long g_stats[3][HRT_STATS_COLS];
 #define HRT_STAT(kind, idx, val)                                                      \
     do {                                                                              \
         if (lane == 0) atomicAdd(&g_stats[kind][idx], (unsigned long long)(val));     \
@@ -807,15 +807,248 @@ __device__ __forceinline__ Hit closest_hit_tree(TriPtr tri, TgPtr tg, LeafPtr le
     return {who, best};
 }
 
+// =====================================================================================
+// Acceleration structure, big tables (more than HRT_ACCEL_BIG triangles): 64-ary levels of
+// bounding spheres over the leaves, the plane tree for the guard, and splitting of packets that are
+// too wide to cull.
+//
+//   * A sphere node (any level) is dropped when every line of the packet misses it by
+//     m >= max(Lambda / 2, mu S): with that margin a triangle below it whose plane is NOT nearly
+//     parallel to the rays -- |d.n| > Gamma_i = (12 / mu) qs_i for every ray -- is rejected by the
+//     reference whatever else holds (lemma above, first term: l <= 2 m gives phi >= m / 4, and
+//     m <= S gives S + l <= 3 S).
+//   * The triangles with |d.n| <= Gamma_i for some ray of the packet are found through the PLANE
+//     TREE (triangles sorted by normal direction; a node is a cone of normals and is skipped when
+//     the packet's directions stay clear of all its planes), and each is then judged on its own:
+//     its ball (p1, l) against the packet's lines, and the lemma with that margin.  Whatever is not
+//     cleared goes through packet_culls and the staged test like the triangles of near leaves (a
+//     triangle reached both ways is tested twice: same result).
+//   * A packet too wide to cull (half-angle > 60 deg: the rays of the wave bounced off different
+//     surfaces) takes one staged pass over the whole table, as in the flat walk.
+// All control flow is wave-uniform; per-wave scratch (node masks, queue of candidate masks, range
+// stack) lives in LDS.
+// =====================================================================================
+constexpr float kMu = (float)HRT_GUARD_MU;
+constexpr float kGammaPerQs = (float)(12.0 / HRT_GUARD_MU);
+
+template <typename TriPtr, typename LeafPtr>
+__device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const hrt_kaccel &A,
+                                               uint32_t num_tri, F3 o, F3 d, bool valid, uint32_t lane,
+                                               const bool shadow, F3 apex, unsigned long long *wmask,
+                                               uint32_t *ws, [[maybe_unused]] int kind)
+{
+    const uint32_t *__restrict__ orig = A.orig;
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
+    if (HRT_BALLOT(valid) == 0ull) return {who, best};
+    // per-wave scratch words: [0..15] queue tags, [16..23] node masks of up to 4 levels (u64),
+    // [24..27] their bases, [32..47] lane-range stack
+    unsigned long long *nmask = reinterpret_cast<unsigned long long *>(ws + 16);
+    uint32_t *nbase = ws + 24, *rstack = ws + 32;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](unsigned long long v) {
+        return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | (unsigned long long)uni((uint32_t)v);
+    };
+    // A packet too wide to cull (the rays of the wave scattered off different surfaces) takes ONE
+    // staged pass over the whole table at the end -- like the flat walk.  Cutting such a wave into
+    // lane ranges, down to single rays, and walking the tree for each was measured and lost at every
+    // size tried (city, T = 25 002: 192 ms with ranges down to single rays, 62 ms down to 8 lanes,
+    // 31 ms with the one pass): a tree walk is a chain of dependent loads, the staged pass streams.
+    // HRT_ACCEL_DEBUG bit 3 (8) re-enables the cutting for experiments.
+    const uint32_t min_range = (A.dbg & 8u) ? ((A.dbg & 4u) ? 8u : 1u) : 64u;
+    unsigned long long unresolved = 0ull;
+    uint32_t rs = 0;
+    if (lane == 0) rstack[0] = 0u | (64u << 8);
+    rs = 1;
+    while (rs > 0) {
+        --rs;
+        const uint32_t rg = uni(rstack[rs]);
+        const uint32_t lo = rg & 0xffu, hi = rg >> 8;
+        const bool sub = valid && lane >= lo && lane < hi;
+        const unsigned long long inval = HRT_BALLOT(!sub);
+        if (inval == ~0ull) continue;
+        const Ball B = origin_ball(o, sub);
+        const Packet P = packet_bounds(B, d, sub, shadow, apex);
+        if (lo == 0 && hi == 64) {
+            HRT_STAT(kind, 0, 1);
+            HRT_STAT(kind, 1, P.usable ? 1 : 0);
+        }
+        if (!P.usable) {
+            if (hi - lo > min_range) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (lane == 0) {
+                    rstack[rs] = mid | (hi << 8);
+                    rstack[rs + 1] = lo | (mid << 8);
+                }
+                rs += 2;
+            } else {
+                unresolved |= ~inval;
+            }
+            continue;
+        }
+        HRT_STAT(kind, 6, 1);
+        uint32_t qn = 0;
+        auto flush = [&]() {
+            for (uint32_t e = 0; e < qn; ++e) {
+                const uint32_t tag = uni(ws[e]);
+                unsigned long long m = uni64(wmask[e]);
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint32_t j = (tag & 0x80000000u) ? A.pl_index[(tag & 0x7fffffffu) * 64u + b]
+                                                           : tag * 64u + b;
+                    HRT_STAGED_BODY(j)
+                }
+            }
+            qn = 0;
+        };
+        auto enqueue = [&](uint32_t tag, unsigned long long m) {
+            if (m == 0ull) return;
+            if (lane == 0) { ws[qn] = tag; wmask[qn] = m; }
+            if (++qn == kMaskRounds) flush();
+        };
+        // ---- sphere levels: level L = top (<= 64 nodes) ... level 0 = leaves ----
+        {
+            const uint32_t L = A.num_levels;
+            auto visit = [&](uint32_t k, uint32_t base) -> unsigned long long {
+                const uint32_t count = (k == 0u) ? A.num_leaf : (k == 1u ? A.node_count[0] : (k == 2u ? A.node_count[1] : A.node_count[2]));
+                const uint32_t idx = base + lane;
+                const bool has = idx < count;
+                const uint32_t ic = has ? idx : base;
+                float4 n0, n1;
+                if (k == 0u) { n0 = leaf[2u * ic]; n1 = leaf[2u * ic + 1u]; }
+                else {
+                    const float4 *arr = reinterpret_cast<const float4 *>(k == 1u ? A.node[0] : (k == 2u ? A.node[1] : A.node[2]));
+                    n0 = arr[2u * ic]; n1 = arr[2u * ic + 1u];
+                }
+                const LeafFar f = leaf_far(P, n0, n1);
+                const bool far = f.m > fmaxf(0.5f * n1.x, kMu * f.S);   // NaN / inf: not far
+                HRT_STAT(kind, 8, 1);
+                return HRT_BALLOT(has && !far);
+            };
+            uint32_t k = L;
+            {
+                const unsigned long long m0 = visit(k, 0u);
+                if (lane == 0) { nmask[k] = m0; nbase[k] = 0u; }
+            }
+            for (;;) {
+                const unsigned long long m = uni64(nmask[k]);
+                if (m == 0ull) {
+                    if (k == L) break;
+                    ++k;
+                    continue;
+                }
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                const uint32_t idx = uni(nbase[k]) + b;
+                if (lane == 0) nmask[k] = m & (m - 1ull);
+                if (k == 0u) {   // a near leaf: packet culling over its 64 rows
+                    const uint32_t jl = idx * 64u + lane;
+                    bool cand = jl < num_tri;
+                    if (cand)
+                        cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
+                                             tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 3],
+                                             tri[HRT_ROW * jl + 4]);
+                    const unsigned long long cm = HRT_BALLOT(cand);
+                    HRT_STAT(kind, 2, __popcll(cm));
+                    HRT_STAT(kind, 7, 1);
+                    enqueue(idx, cm);
+                } else {
+                    --k;
+                    const unsigned long long mk = visit(k, idx * 64u);
+                    if (lane == 0) { nmask[k] = mk; nbase[k] = idx * 64u; }
+                }
+            }
+        }
+        // ---- plane tree: level pl_levels-1 = top ... level 0 = cones of the 64-entry leaves ----
+        if (!(A.dbg & 2u)) {
+            const uint32_t L = A.pl_levels - 1u;
+            auto visit = [&](uint32_t k, uint32_t base) -> unsigned long long {
+                const uint32_t count = k == 0u ? A.pl_count[0] : (k == 1u ? A.pl_count[1] : A.pl_count[2]);
+                const float4 *arr = reinterpret_cast<const float4 *>(k == 0u ? A.pl_node[0] : (k == 1u ? A.pl_node[1] : A.pl_node[2]));
+                const uint32_t idx = base + lane;
+                const bool has = idx < count;
+                const uint32_t ic = has ? idx : base;
+                const float4 n0 = arr[2u * ic], n1 = arr[2u * ic + 1u];
+                const float sdot = fabsf(fdot3(P.ax, {n0.x, n0.y, n0.z}));
+                // every member plane is clear of the packet's directions by more than its Gamma:
+                // elevation of ax over the planes > alpha + beta + g
+                const float thr = __builtin_fmaf(P.sina, n1.x, P.cosa * n0.w) * 1.0001f + 1e-6f;
+                const bool skip = sdot > thr;                    // NaN: visit
+                HRT_STAT(kind, 9, 1);
+                return HRT_BALLOT(has && !skip);
+            };
+            uint32_t k = L;
+            {
+                const unsigned long long m0 = visit(k, 0u);
+                if (lane == 0) { nmask[k] = m0; nbase[k] = 0u; }
+            }
+            for (;;) {
+                const unsigned long long m = uni64(nmask[k]);
+                if (m == 0ull) {
+                    if (k == L) break;
+                    ++k;
+                    continue;
+                }
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                const uint32_t idx = uni(nbase[k]) + b;
+                if (lane == 0) nmask[k] = m & (m - 1ull);
+                if (k == 0u) {   // a leaf of 64 triangle ids: each judged on its own
+                    const uint32_t e = idx * 64u + lane;
+                    const uint32_t j = A.pl_index[e];
+                    const float4 *rec = reinterpret_cast<const float4 *>(A.pl_rec) + 2u * e;
+                    const float4 r0 = rec[0], r1 = rec[1];
+                    bool cand = j != HRT_NO_HIT;
+                    HRT_STAT(kind, 10, 1);
+                    if (cand) {
+                        const F3 n = {r1.x, r1.y, r1.z};
+                        const float amin = __builtin_fmaf(fabsf(fdot3(P.ax, n)), P.cosa, -P.sina);
+                        bool safe = amin > kGammaPerQs * r1.w;           // the spheres vouch for it
+                        if (!safe) {
+                            const LeafFar f = leaf_far(P, r0, make_float4(r0.w, 0.f, 0.f, 0.f));   // ball (p1, l)
+                            const F3 sb = sub3(P.bc, {r0.x, r0.y, r0.z});
+                            const float hmin = fabsf(fdot3(n, sb)) - P.br * 1.0001f -
+                                               2e-6f * ((fabsf(sb.x) + fabsf(sb.y)) + fabsf(sb.z));
+                            const float Ti = r1.w * (f.S + r0.w);
+                            safe = (f.m > 0.f) & ((amin * f.phi > Ti) | (hmin * f.kappa > Ti));
+                        }
+                        cand = !safe;
+                    }
+                    if (HRT_BALLOT(cand) != 0ull) {
+                        HRT_STAT(kind, 11, 1);
+                        HRT_STAT(kind, 12, __popcll(HRT_BALLOT(cand)));
+                        if (cand) {
+                            const uint32_t jc = j;
+                            cand = !packet_culls(P, tri[HRT_ROW * jc], tri[HRT_ROW * jc + 1],
+                                                 tri[HRT_ROW * jc + 2], tri[HRT_ROW * jc + 3],
+                                                 tri[HRT_ROW * jc + 4]);
+                        }
+                        enqueue(idx | 0x80000000u, HRT_BALLOT(cand));
+                    }
+                } else {
+                    --k;
+                    const unsigned long long mk = visit(k, idx * 64u);
+                    if (lane == 0) { nmask[k] = mk; nbase[k] = idx * 64u; }
+                }
+            }
+        }
+        flush();
+    }
+    if (unresolved != 0ull) {   // every triangle, exactly (also: single rays with a NaN or zero direction)
+        const unsigned long long inval = ~unresolved;
+        for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
+    }
+    return {who, best};
+}
+
 #ifndef HRT_TRACE_VARIANT_DEFAULT
-#define HRT_TRACE_VARIANT_DEFAULT 4
+#define HRT_TRACE_VARIANT_DEFAULT 7   /* auto */
 #endif
 
 // Called by ALL lanes of a wave (uniform control flow); lanes with valid == false carry a dummy
 // ray and their result is meaningless.  VARIANT: 0 plain, 1 staged, 2 / 3 flat packet culling
 // (one block / many), 4 / 5 packet culling behind the leaf spheres + guard (one block / many).
 template <int VARIANT, typename TriPtr, typename TgPtr, typename LeafPtr>
-__device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf,
+__device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, const hrt_kaccel &A,
                                            const uint32_t *__restrict__ orig, uint32_t num_tri, F3 o,
                                            F3 d, bool valid, uint32_t lane, const Ball &B,
                                            const bool shadow, F3 apex, unsigned long long *wmask,
@@ -832,6 +1065,9 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf,
     } else if constexpr (VARIANT == 2 || VARIANT == 3) {
         return closest_hit_packet<(VARIANT == 3)>(tri, orig, num_tri, o, d, valid, lane, B, shadow, apex,
                                                   wmask, kind);
+    } else if constexpr (VARIANT == 6) {
+        return closest_hit_big(tri, leaf, A, num_tri, o, d, valid, lane, shadow, apex, wmask,
+                               reinterpret_cast<uint32_t *>(wleaf), kind);
     } else {
         return closest_hit_tree<(VARIANT == 5)>(tri, tg, leaf, orig, num_tri, o, d, valid, lane, B, shadow,
                                                 apex, wmask, wleaf, kind);
@@ -1103,7 +1339,19 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     }();
     const uint32_t lane = tid & 63u;
 
-    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    // Units are dealt statically (unit = blockIdx + k * gridDim) -- except on big tables, where one
+    // trace can cost a hundred times another (a wave whose rays scattered is walked ray by ray):
+    // there the workgroups pull units from a counter (one returning atomic per unit: ~1 us against
+    // units of tens of us; on small tables the static deal is cheaper).
+    uint32_t *unit_ctr = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + 256u) + b;
+    for (uint32_t unit = blockIdx.x;; unit += gridDim.x) {
+        if constexpr (VARIANT == 6) {
+            if (tid == 0) l_wcnt[0] = atomicAdd(unit_ctr, 1u);
+            __syncthreads();
+            unit = l_wcnt[0];
+            __syncthreads();
+        }
+        if (unit >= n_units) break;
         const uint32_t chunk = unit / kinds;
         const uint32_t k = k_lo + (unit - chunk * kinds);
         const uint32_t i = chunk * HRT_BLOCK + tid;
@@ -1133,9 +1381,19 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
             if (valid) d = w;
         }
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
-        if constexpr (VARIANT >= 2) ball = origin_ball(o, valid);
-        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc.orig, T, o, d, valid, lane, ball, shadow,
+        if constexpr (VARIANT >= 2 && VARIANT != 6) ball = origin_ball(o, valid);
+#ifdef HRT_KERNEL_STATS
+        const long long t_unit0 = clock64();
+#endif
+        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.acc.orig, T, o, d, valid, lane, ball, shadow,
                                            apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
+#ifdef HRT_KERNEL_STATS
+        if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks
+            const unsigned long long dt = (unsigned long long)(clock64() - t_unit0);
+            atomicMax(&g_stats[shadow ? 2 : (first ? 0 : 1)][13], dt);
+            atomicAdd(&g_stats[shadow ? 2 : (first ? 0 : 1)][14], dt);
+        }
+#endif
         if (valid) {
             stu(res_blk(P, k), 0u, i4, h.tri);
             stf(res_blk(P, k), cap4, i4, h.t);
@@ -1634,10 +1892,12 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
-    // HRT_TRACE_VARIANT: 4 = packet culling behind the leaf spheres + guard (default), 2 = flat
-    // packet culling, 1 = staged tests over all triangles, 0 = the reference's plain sequence.  All
-    // give bit-identical results; 0-2 are kept for A/B timing and as in-library cross-checks (the
-    // GPU tests run all).
+    // HRT_TRACE_VARIANT: unset = auto: the trees (inner sphere levels + plane tree) where the host
+    // built them -- big, sparse tables, csrc/host/accel.c -- and flat packet culling elsewhere
+    // (measured: on small and on dense tables the leaf spheres never pay: C3 1.81 vs 1.76 ms).
+    // 6 = trees wherever built, else 4; 4 = packet culling behind the leaf spheres + guard; 2 = flat
+    // packet culling; 1 = staged tests over all triangles; 0 = the reference's plain sequence.  All
+    // give bit-identical results; the GPU tests run all of them.
     static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
     const uint64_t T = P->num_tri;
     // staged image: rows + guard pairs (padded to 16 B) + leaf records
@@ -1651,18 +1911,22 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
+    const bool trees = P->acc.big && (variant >= 4);
+    const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees);
     if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
-        else if (variant == 2 || variant == 3) {
+        else if (flat) {
             if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
             else launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
-        } else if (one_block) launch_trace_t<true, 4>(P, bounce, nb, lds, st, &err);
+        } else if (trees) launch_trace_t<true, 6>(P, bounce, nb, lds, st, &err);
+        else if (one_block) launch_trace_t<true, 4>(P, bounce, nb, lds, st, &err);
         else launch_trace_t<true, 5>(P, bounce, nb, lds, st, &err);
     } else {
         if (variant == 0) launch_trace_t<false, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<false, 1>(P, bounce, nb, lds, st, &err);
-        else if (variant == 2 || variant == 3) launch_trace_t<false, 3>(P, bounce, nb, lds, st, &err);
+        else if (flat) launch_trace_t<false, 3>(P, bounce, nb, lds, st, &err);
+        else if (trees) launch_trace_t<false, 6>(P, bounce, nb, lds, st, &err);
         else launch_trace_t<false, 5>(P, bounce, nb, lds, st, &err);   // tables beyond LDS are > 1 block
     }
     if (err != hipSuccess) return (int)err;
@@ -1702,19 +1966,19 @@ int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, v
     return (int)hipGetLastError();
 }
 
-int hrt_hip_read_stats(unsigned long long *out24, int reset)
+int hrt_hip_read_stats(unsigned long long *out, int reset)
 {
 #ifdef HRT_KERNEL_STATS
-    hipError_t e = hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 24);
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 3 * HRT_STATS_COLS);
     if (e != hipSuccess) return (int)e;
     if (reset) {
-        unsigned long long z[24] = {0};
+        unsigned long long z[3 * HRT_STATS_COLS] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z);
     }
     return (int)e;
 #else
     (void)reset;
-    for (int i = 0; i < 24; ++i) out24[i] = 0;
+    for (int i = 0; i < 3 * HRT_STATS_COLS; ++i) out[i] = 0;
     return 0;
 #endif
 }

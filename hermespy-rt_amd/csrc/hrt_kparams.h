@@ -36,9 +36,10 @@ extern "C" {
 #define HRT_NODE_FLOATS 8           /* a sphere node: c.xyz, R, Lambda, -, -, -; a cone node: nu.xyz,
                                      * sin(beta+g), cos(beta+g); a guard record: p1.xyz, l, n.xyz, qs */
 #define HRT_ACCEL_MAX_LEVELS 3      /* 64-ary levels above the leaves: up to 64^4 = 16.7 M triangles */
-#define HRT_ACCEL_BIG 4096u         /* tables with more triangles get inner levels + the plane tree */
+#define HRT_ACCEL_BIG 65536u        /* tables with more triangles get inner levels + the plane tree ... */
+#define HRT_ACCEL_SPARSE 0.05       /* ... if the median leaf radius is below this fraction of the scene's */
 #define HRT_GUARD_SF 4.0            /* safety factor on the reference's noise bound 1e-5 l (S + l) */
-#define HRT_GUARD_MU 0.0625         /* big tables: a sphere is "far" when missed by mu * S and Lambda */
+#define HRT_GUARD_MU 0.0625         /* big tables: a sphere is "far" when missed by mu * S and Lambda / 2 */
 
 typedef struct {
     const uint32_t *orig;           /* [T] table row -> index in the reference's loop order */
@@ -46,6 +47,8 @@ typedef struct {
     const float *leaf;              /* [num_leaf][HRT_NODE_FLOATS] */
     uint32_t num_leaf;
     uint32_t big;                   /* inner levels + plane tree present */
+    uint32_t dbg;                   /* HRT_ACCEL_DEBUG bits (timing experiments only): 2 skip the plane tree
+                                     * (UNSOUND), 8 cut unusable packets into lane ranges (4: down to 8 lanes) */
     uint32_t num_levels;
     uint32_t node_count[HRT_ACCEL_MAX_LEVELS];
     const float *node[HRT_ACCEL_MAX_LEVELS];
@@ -106,7 +109,8 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
-int hrt_hip_read_stats(unsigned long long *out24, int reset);
+#define HRT_STATS_COLS 16
+int hrt_hip_read_stats(unsigned long long *out3xCOLS, int reset);
 /* events: opaque handles */
 int hrt_hip_event_create(void **ev);
 int hrt_hip_event_destroy(void *ev);

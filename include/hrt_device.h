@@ -230,11 +230,14 @@ int hrt_scene_import_sionna(const char *xml_path, Scene *out);
  * the result with the host libm. */
 int hrt_selftest_math(int device, int fn, const float *in, float *out, uint64_t n);
 
-/* Diagnostic counters of the packet-culling loop; all zero unless the library was built with
- * `make STATS=1`.  out24 = [3 kinds][8]: kind 0 primary traces of launch 0, 1 primary traces
- * of later launches, 2 shadow traces; columns: wave-traces, usable packets, candidate
- * triangles, staged bodies reaching stage 2, stage 3, the exact divisions, -, -. */
-int hrt_debug_kernel_stats(int device, uint64_t *out24, int reset);
+/* Diagnostic counters of the trace kernel; all zero unless the library was built with
+ * `make STATS=1`.  out48 = [3 kinds][16]: kind 0 primary traces of launch 0, 1 primary traces
+ * of later launches, 2 shadow traces; columns: 0 wave-traces, 1 packets usable as a whole,
+ * 2 candidate triangles after packet culling, 3 / 4 / 5 staged bodies reaching stage 2, stage 3,
+ * the exact divisions, 6 (sub-)packets walked [flat: heavy packets], 7 packet-culling rounds of near
+ * leaves [flat: candidates of heavy packets], 8 sphere-node rounds, 9 plane-node rounds, 10 plane
+ * leaves judged, 11 of them with flagged triangles, 12 flagged triangles, 13-15 unused. */
+int hrt_debug_kernel_stats(int device, uint64_t *out48, int reset);
 
 #ifdef __cplusplus
 }

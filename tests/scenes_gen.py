@@ -65,6 +65,44 @@ def room_with_clutter(path, n_boxes, seed=1, moving=True, tilt=False, scale=1.0,
     return 12 * (n_boxes + 1)
 
 
+def city(path, n_side, seed=3, pitch=30.0, max_meshes=900, moving=False):
+    """A Sionna-like city block grid: n_side x n_side buildings (boxes without a bottom face: 10
+    triangles each; footprints 12-24 m, heights 8-60 m, each turned a few degrees about z) on a
+    `pitch` metre grid, over a two-triangle ground plane.  10 * n_side^2 + 2 triangles; consecutive
+    buildings share a mesh beyond max_meshes.  Returns (triangle count, half extent)."""
+    rng = np.random.default_rng(seed)
+    half = 0.5 * n_side * pitch
+    g = np.array([[-half - 50, -half - 50, 0], [half + 50, -half - 50, 0], [half + 50, half + 50, 0],
+                  [-half - 50, half + 50, 0]], np.float32)
+    meshes = [dict(vs=g, idx=np.array([[0, 1, 2], [0, 2, 3]], np.uint32), material_index=1, velocity=[0, 0, 0])]
+    n = n_side * n_side
+    per = max(1, -(-n // max_meshes))
+    cur = None
+    k = 0
+    for iy in range(n_side):
+        for ix in range(n_side):
+            cx, cy = (ix + 0.5) * pitch - half, (iy + 0.5) * pitch - half
+            w, dpt, h = rng.uniform(12, 24), rng.uniform(12, 24), rng.uniform(8, 60)
+            v, f = _box([cx, cy, h / 2], [w, dpt, h])
+            a = rng.uniform(-0.2, 0.2)
+            Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            c = np.array([cx, cy, h / 2])
+            v = ((v - c) @ Rz.T + c).astype(np.float32)
+            # drop the bottom face (z = 0): the two triangles whose vertices all have the lowest z
+            zmin = v[:, 2].min()
+            f = np.array([t for t in f if not np.all(np.isclose(v[t, 2], zmin))], np.uint32)
+            if k % per == 0:
+                vel = rng.uniform(-10, 10, 3) if (moving and (k // per) % 5 == 0) else np.zeros(3)
+                cur = dict(vs=v, idx=f, material_index=(k // per) % 17, velocity=vel)
+                meshes.append(cur)
+            else:
+                cur["idx"] = np.concatenate([cur["idx"], f + len(cur["vs"])]).astype(np.uint32)
+                cur["vs"] = np.concatenate([cur["vs"], v]).astype(np.float32)
+            k += 1
+    write_hrt(path, meshes)
+    return 10 * n + 2, half
+
+
 def nasty(path):
     """Ties and degeneracies: a floor quad given twice (every floor hit is an exact tie between
     two different (mesh, face) pairs), two triangles sharing an edge hit exactly, a zero-area

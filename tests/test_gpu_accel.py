@@ -1,0 +1,87 @@
+"""The acceleration structure (csrc/host/accel.c, closest_hit_tree / closest_hit_big
+in csrc/hrt_kernels.hip; reference: the "TODO BVH" of src/compute_paths.c:246, semantics :237-287).
+
+Whatever the structure skips must be exactly what the reference's float test rejects, including
+its noise-regime hits on triangles whose plane contains the ray -- so every case is the product
+against the oracle, every output array bit for bit:
+  * the modes: leaf spheres + guard (HRT_TRACE_VARIANT=4), inner levels + plane tree
+    forced onto small tables (HRT_ACCEL_BIG=0: every scene of the suite then walks the trees),
+    the reference's own order (HRT_NO_REORDER=1), the flat walk (2) -- on generated scenes,
+    exact ties (duplicated triangles: the lexicographic (distance, original index) tie-break),
+    endpoints exactly IN triangle planes, degenerate triangles;
+  * a generated city of 10^5 triangles (tests/scenes_gen.city) with the trees on by default.
+The variant and the table order are latched per process / per problem: subprocesses."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r"""
+import sys, tempfile
+sys.path.insert(0, %(repo)r)
+from hermespy_rt_amd import abi, lib
+from oracle import oracle
+from tests import configs as K
+from tests.parity import compare_dense
+from tests.test_generated_scenes import make, NAMES
+tmp = tempfile.mkdtemp()
+cases = [make(tmp, n) for n in NAMES] + [K.small(K.C3, 20000), K.small(K.C4_DOPPLER, 5000), K.small(K.C5, 1024)]
+cases += list(K.IN_PLANE.values())
+for c in cases:
+    got = abi.run_compute_paths(lib.load(), *K.args(c))
+    ref = oracle.compute_paths(*K.args(c))
+    st = compare_dense(got, ref)
+    assert all(v == 0 for v in st.values()), (c["scene_path"], st)
+print("ACCEL_OK", len(cases))
+"""
+
+
+@pytest.mark.parametrize("env", [
+    dict(HRT_TRACE_VARIANT="4"),                   # leaf spheres + guard
+    dict(HRT_ACCEL_BIG="0"),                       # inner levels + plane tree on every table (auto picks them)
+    dict(HRT_ACCEL_BIG="0", HRT_ACCEL_DEBUG="8"),  # ... with unusable packets cut down to single rays
+    dict(HRT_ACCEL_BIG="0", HRT_NO_REORDER="1"),   # ... on the reference's own table order
+    dict(HRT_TRACE_VARIANT="2"),                   # flat packet culling on the reordered table
+    dict(HRT_TRACE_VARIANT="0", HRT_NO_REORDER="1"),
+], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "plain_ref_order"])
+def test_modes_are_bit_identical_to_the_oracle(env):
+    p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and "ACCEL_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+CITY = r"""
+import sys, tempfile, os, time
+sys.path.insert(0, %(repo)r)
+import numpy as np
+from hermespy_rt_amd import abi, lib
+from oracle import oracle
+from tests import configs as K, scenes_gen as G
+from tests.parity import compare_dense
+p = os.path.join(tempfile.mkdtemp(), "city.hrt")
+T, half = G.city(p, 100, moving=True)
+assert T == 100002
+c = G.cfg(p, [[60.0, 0.0, 1.5], [0.0, -90.0, 1.5], [-150.0, 30.0, 1.5]], [[0.0, 0.0, 25.0]], 6000, 3,
+          rx_vel=[[1, 2, 0], [0, -3, 1], [2, 0, 0]], tx_vel=[[10, 0, 0]])
+t0 = time.time()
+got = abi.run_compute_paths(lib.load(), *K.args(c))
+t1 = time.time()
+ref = oracle.compute_paths(*K.args(c))
+st = compare_dense(got, ref)
+assert all(v == 0 for v in st.values()), st
+live = [int(x) for x in ref["extras"]["live"]]
+assert live[1] > 3000 and live[3] > 500, live
+print("CITY_OK", live, "product %%.1f s, oracle %%.1f s" %% (t1 - t0, time.time() - t1))
+"""
+
+
+@pytest.mark.parametrize("env", [dict(), dict(HRT_TRACE_VARIANT="2")], ids=["trees", "flat"])
+def test_city_of_1e5_triangles(env):
+    """10^5 triangles: above HRT_ACCEL_BIG and sparse, so the trees are on by default."""
+    p = subprocess.run([sys.executable, "-c", CITY % dict(repo=REPO)], env=dict(os.environ, **env),
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and "CITY_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
