@@ -1,12 +1,9 @@
 """ctypes mirror of the reference's C ABI for the compute_paths hot path.
 
 This is the host-side (Python) statement of the drop-in boundary.  Every struct below is
-byte-compatible with the reference header it cites, so the SAME driver code can call
-
-  * the product library  (hermespy-rt_amd/lib/libhermespy_rt_amd.so, HIP path), and
-  * the real reference   (oracle/_ref/libhrt_ref.so, built in place from /root/reference),
-
-which is what lets tests/ run one harness against both.
+byte-compatible with the reference header it cites, so driver code written against these
+declarations works with any library that exports the reference's three entry points -- the
+product loads its own (lib.py); tests/ use the same declarations to drive the checker builds.
 
 Reference interface mirrored here:
   Vec3            inc/vec3.h:6-8
@@ -81,8 +78,9 @@ assert C.sizeof(ChannelInfo) == 72 and C.sizeof(RaysInfo) == 24
 SENTINEL_U32 = 0x7FC0DEAD
 
 
-def bind_reference_abi(lib):
-    """Declare argtypes/restype of the three reference entry points on `lib`."""
+def bind_c_abi(lib):
+    """Declare argtypes/restype of compute_paths / scene_load / scene_save (the reference's
+    signatures, inc/compute_paths.h:59-74, inc/scene.h:95-105) on the loaded library `lib`."""
     lib.scene_load.argtypes = [C.c_char_p]
     lib.scene_load.restype = Scene
     lib.scene_save.argtypes = [C.POINTER(Scene), C.c_char_p]

@@ -8,9 +8,8 @@
  *   Q2  slots of dead rays, and directions/freq_shift of blocked records, are not touched
  *   Q3  a blocked LoS pair leaves its directions/freq_shift untouched
  *   Q9  scatter freq_shift launch term + memcpy replication (src/compute_paths.c:494-508)
- *   Q10 the "+= 0" on freq_shift[tx*np+path] (:663-664); replayed for num_tx == 1, where the
- *       slot belongs to the same ray (for num_tx > 1 it only ever adds an exact zero to
- *       another ray's slot and is skipped)
+ *   Q10 the "+= 0" on freq_shift[tx*np+path] (:663-664): replayed in the reference's (bounce, tx)
+ *       order -- it can turn a -0 into +0, or a slot into NaN for a non-finite mesh velocity
  *   Q11/Q12/Q14 RaysInfo snapshot offsets use stride num_bounces, the active-mask snapshot is
  *       always taken from byte 0, dead rays keep their last origin/direction
  *
@@ -67,6 +66,8 @@ int hrt_host_threads(void)
         long nc = sysconf(_SC_NPROCESSORS_ONLN);
         t = nc > 16 ? 16 : (nc > 0 ? (int)nc : 1);
     }
+    /* every per-thread array of the host writers has HRT_MAX_SCATTER_THREADS entries */
+    if (t > HRT_MAX_SCATTER_THREADS) t = HRT_MAX_SCATTER_THREADS;
     return t;
 }
 
@@ -98,6 +99,8 @@ typedef struct {
     Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
     uint8_t *active, *next_active;
     float *dirs_batch;      /* gathered launch directions of one batch */
+    uint64_t *run_start;    /* per bounce: runs of equal TX in the hit list */
+    uint32_t *run_tx;
     int device;
 } work_t;
 
@@ -166,6 +169,7 @@ static void work_free(work_t *w)
     hrt_hip_host_free(w->mask);
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec2[k]);
     hrt_hip_host_free(w->mask2);
+    free(w->run_start); free(w->run_tx);
     free(w->dirs_batch); free(w->cur_rays); free(w->active); free(w->next_active);
 }
 
@@ -175,7 +179,7 @@ typedef struct {
     float *const *rec;
     const uint64_t *mask;
     ChannelInfo *scat;
-    uint64_t n_loc;
+    uint64_t n_loc, i_base;   /* the range handed to scatter_range is relative to i_base */
     size_t rx, b, ntx, nb, np;
     uint64_t unblocked[HRT_MAX_SCATTER_THREADS];
 } scatter_ctx;
@@ -186,7 +190,7 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     scatter_ctx *c = (scatter_ctx *)vctx;
     ChannelInfo *scat = c->scat;
     uint64_t unb = 0;
-    for (uint64_t i = i0; i < i1; ++i) {
+    for (uint64_t i = c->i_base + i0; i < c->i_base + i1; ++i) {
         const uint32_t ql = c->ray[i];
         const size_t tx = ql / c->n_loc;
         const uint64_t p = hrt_shard_global_path(c->s, ql - tx * c->n_loc);
@@ -240,7 +244,9 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         uint32_t j = 0;
         for (uint32_t i = 0; i < scene->num_meshes; ++i) {
             Mesh *m = &scene->meshes[i];
-            free(m->ns);
+            /* like the reference (:212) the old pointer is overwritten, NOT freed: a caller that
+             * built the Mesh by hand may have left `ns` uninitialised or pointing at memory that is
+             * not malloc'ed, which is legal against the reference ABI */
             m->ns = (Vec3 *)malloc((size_t)(m->num_triangles ? m->num_triangles : 1) * sizeof(Vec3));
             if (!m->ns) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
             for (uint32_t f = 0; f < m->num_triangles; ++f, ++j)
@@ -249,49 +255,28 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     }
     st.t_setup_s = hrt_now_s() - t_begin;
 
-    /* ---- launch directions of the whole sphere (host libm, threads) ---- */
+    /* ---- launch tables.  Default: generated ON THE DEVICE (directions bit-identical to the host
+     * libm's, hrt_launch_dirs_device; coherent order by hrt_launch_order_device), after the buffers
+     * exist (below).  HRT_HOST_LAUNCH=1: the host generators + the launch-table cache. ---- */
+    const int host_launch = env_int("HRT_HOST_LAUNCH", 0);
     double t0 = hrt_now_s();
     hrt_shard whole = {np, 0, 1, 0, (uint32_t)nb};
-    w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
-    if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-    if (!(hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, w.h_dirs, NULL))) {
-        rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
-        if (rc) goto done;
-        hrt_launch_cache_put(np, w.h_dirs, NULL);
-    }
-    st.t_launch_dirs_s = hrt_now_s() - t0;
-
-    /* ---- dense pre-fills that do not depend on the trace ---- */
-    /* Q9, literally: launch term at [tx*np*nb + p], then the two memcpy replications */
-    for (size_t tx = 0; tx < ntx; ++tx)
-        for (size_t p = 0; p < np; ++p) {
-            const float *d = w.h_dirs + 3 * p;
-            float v = tx_vel[tx].x * d[0] + tx_vel[tx].y * d[1] + tx_vel[tx].z * d[2];
-            scat->freq_shift[tx * np * nb + p] = v * prob->dop_mult;
+    if (host_launch) {
+        w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
+        if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+        if (!(hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, w.h_dirs, NULL))) {
+            rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
+            if (rc) goto done;
+            hrt_launch_cache_put(np, w.h_dirs, NULL);
         }
-    for (size_t b = 1; b < nb; ++b)
-        memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
-    for (size_t rx = 1; rx < nrx; ++rx)
-        memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
-
-    if (scat_rays) {
-        /* :469-471 and :589 */
-        for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
-        w.cur_rays = (Ray *)malloc(nq * sizeof(Ray));
-        w.active = (uint8_t *)malloc(nq / 8 + 1);
-        w.next_active = (uint8_t *)malloc(nq / 8 + 1);
-        if (!w.cur_rays || !w.active || !w.next_active) {
-            rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
-            goto done;
-        }
-        memset(w.active, 0xff, nq / 8 + 1);
+        st.t_launch_dirs_s = hrt_now_s() - t0;
+        /* Q9, literally: launch term at [tx*np*nb + p] (the memcpy replications follow below) */
         for (size_t tx = 0; tx < ntx; ++tx)
             for (size_t p = 0; p < np; ++p) {
-                Ray *r = &w.cur_rays[tx * np + p];
-                r->o = tx_pos[tx];
-                memcpy(&r->d, w.h_dirs + 3 * p, sizeof(Vec3));
+                const float *d = w.h_dirs + 3 * p;
+                float v = tx_vel[tx].x * d[0] + tx_vel[tx].y * d[1] + tx_vel[tx].z * d[2];
+                scat->freq_shift[tx * np * nb + p] = v * prob->dop_mult;
             }
-        memcpy(scat_rays->rays, w.cur_rays, nq * sizeof(Ray));
     }
 
     /* ---- batches: how many round-robin shards so one workspace fits the budget ---- */
@@ -325,7 +310,7 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         const uint64_t n_loc_max = hrt_shard_num_local(&s0);
         const uint64_t cap = L.cap;
         if ((rc = hrt_device_malloc(w.device, &w.d_ws, L.total_bytes))) goto done;
-        if ((rc = hrt_device_malloc(w.device, &w.d_dirs, n_loc_max * 12))) goto done;
+        if ((rc = hrt_device_malloc(w.device, &w.d_dirs, (n_loc_max + 64) * 12))) goto done;   /* + rounding of a prefill piece */
         if ((rc = hrt_device_malloc(w.device, &w.d_order, n_loc_max * 4))) goto done;
         w.h_order = (uint32_t *)malloc(n_loc_max * 4);
         if (!w.h_order) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
@@ -345,30 +330,94 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
 
     double t_dev = 0.0, t_rb = 0.0;
 
+    if (!host_launch) {
+        /* the launch Doppler term of every path (Q9) from directions generated on the device, in
+         * pieces that fit the direction buffer: a "shard" with one granule per rank is a contiguous
+         * range of the sphere.  With one batch the single piece is the whole launch set and its
+         * directions stay in w.d_dirs for the trace. */
+        t0 = hrt_now_s();
+        const uint64_t n_buf = hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb});
+        uint32_t pieces = (uint32_t)((np + n_buf - 1) / n_buf);
+        uint64_t piece = ((np + pieces - 1) / pieces + 63) / 64 * 64;
+        if (G == 1) { pieces = 1; piece = 0; }
+        for (uint32_t k = 0; k < pieces; ++k) {
+            hrt_shard ps = {np, k, pieces, (uint32_t)piece, (uint32_t)nb};
+            const uint64_t n_p = hrt_shard_num_local(&ps);
+            if (n_p == 0) continue;
+            const uint64_t a = hrt_shard_global_path(&ps, 0);
+            if ((rc = hrt_launch_dirs_device(&ps, (float *)w.d_dirs, w.device, NULL, NULL))) goto done;
+            for (size_t tx = 0; tx < ntx; ++tx) {
+                const float tv[3] = {tx_vel[tx].x, tx_vel[tx].y, tx_vel[tx].z};
+                int e = hrt_hip_launch_fs0((const float *)w.d_dirs, n_p, tv, prob->dop_mult, (float *)w.d_ws, NULL);
+                if (e) { rc = hrt_fail_hip(e, "hrt_fs0_kernel"); goto done; }
+                if ((rc = hrt_device_download(w.device, scat->freq_shift + tx * np * nb + a, w.d_ws, n_p * 4))) goto done;
+            }
+        }
+        if (scat_rays) {   /* RaysInfo needs the directions on the host (one batch: they are in w.d_dirs) */
+            w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
+            if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            if ((rc = hrt_device_download(w.device, w.h_dirs, w.d_dirs, np * 12))) goto done;
+        }
+        st.t_launch_dirs_s += hrt_now_s() - t0;
+    }
+    /* Q9: the two memcpy replications of the launch term */
+    for (size_t b = 1; b < nb; ++b)
+        memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
+    for (size_t rx = 1; rx < nrx; ++rx)
+        memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
+
+    if (scat_rays) {
+        /* :469-471 and :589 */
+        for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
+        w.cur_rays = (Ray *)malloc(nq * sizeof(Ray));
+        w.active = (uint8_t *)malloc(nq / 8 + 1);
+        w.next_active = (uint8_t *)malloc(nq / 8 + 1);
+        if (!w.cur_rays || !w.active || !w.next_active) {
+            rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
+            goto done;
+        }
+        memset(w.active, 0xff, nq / 8 + 1);
+        for (size_t tx = 0; tx < ntx; ++tx)
+            for (size_t p = 0; p < np; ++p) {
+                Ray *r = &w.cur_rays[tx * np + p];
+                r->o = tx_pos[tx];
+                memcpy(&r->d, w.h_dirs + 3 * p, sizeof(Vec3));
+            }
+        memcpy(scat_rays->rays, w.cur_rays, nq * sizeof(Ray));
+    }
+
     for (uint32_t g = 0; g < G; ++g) {
         hrt_shard s = {np, g, G, 0, (uint32_t)nb};
         const uint64_t n_loc = hrt_shard_num_local(&s);
         if (n_loc == 0) continue;
         rc = hrt_layout_query(prob, &s, &L);
         if (rc) goto done;
-        /* this batch's launch directions: gather from the whole-sphere table */
-        const float *src = w.h_dirs;
-        if (G > 1) {
-            if (!w.dirs_batch) w.dirs_batch = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
-            if (!w.dirs_batch) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-            for (uint64_t i = 0; i < n_loc; ++i)
-                memcpy(w.dirs_batch + 3 * i, w.h_dirs + 3 * hrt_shard_global_path(&s, i), 12);
-            src = w.dirs_batch;
+        if (host_launch) {
+            /* this batch's launch directions: gather from the whole-sphere table */
+            const float *src = w.h_dirs;
+            if (G > 1) {
+                if (!w.dirs_batch) w.dirs_batch = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
+                if (!w.dirs_batch) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+                for (uint64_t i = 0; i < n_loc; ++i)
+                    memcpy(w.dirs_batch + 3 * i, w.h_dirs + 3 * hrt_shard_global_path(&s, i), 12);
+                src = w.dirs_batch;
+            }
+            t0 = hrt_now_s();
+            if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, NULL, w.h_order))) {
+                if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
+                if (G == 1) hrt_launch_cache_put(np, w.h_dirs, w.h_order);
+            }
+            st.t_launch_dirs_s += hrt_now_s() - t0;   /* host-side launch preparation */
+            t0 = hrt_now_s();
+            if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;
+            if ((rc = hrt_device_upload(w.device, w.d_order, w.h_order, n_loc * 4))) goto done;
+        } else {
+            t0 = hrt_now_s();
+            if (G > 1 && (rc = hrt_launch_dirs_device(&s, (float *)w.d_dirs, w.device, NULL, NULL))) goto done;
+            if ((rc = hrt_launch_order_device(&s, (uint32_t *)w.d_order, w.device, NULL))) goto done;
+            st.t_launch_dirs_s += hrt_now_s() - t0;
+            t0 = hrt_now_s();
         }
-        t0 = hrt_now_s();
-        if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, NULL, w.h_order))) {
-            if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
-            if (G == 1) hrt_launch_cache_put(np, w.h_dirs, w.h_order);
-        }
-        st.t_launch_dirs_s += hrt_now_s() - t0;   /* host-side launch preparation */
-        t0 = hrt_now_s();
-        if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;
-        if ((rc = hrt_device_upload(w.device, w.d_order, w.h_order, n_loc * 4))) goto done;
         if ((rc = hrt_trace(prob, &s, (const float *)w.d_dirs, (const uint32_t *)w.d_order, w.d_ws, L.total_bytes, NULL, NULL))) goto done;
         if ((rc = hrt_device_sync(w.device, NULL))) goto done;
         t_dev += hrt_now_s() - t0;
@@ -437,48 +486,91 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                     for (int k = 0; k < 6; ++k)
                         DL(w.st[k], hb + (uint64_t)(HRT_HIT_OX + k) * L.cap * 4, H * 4);
             }
-            /* Q10 (num_tx == 1 only): fs[p] += dot(d - d, mesh_velocity) * f/c, before the
-             * records of this ray are applied */
-            if (ntx == 1)
-                for (uint64_t i = 0; i < H; ++i) {
-                    const uint64_t p = hrt_shard_global_path(&s, w.ray[i]);
+            /* Q10: the reference adds dot(d - d, mesh_velocity) * f/c -- a signed zero, or NaN for a
+             * non-finite velocity -- to freq_shift[tx*np + path] of every ray that hit (:663-664),
+             * in its loop order (bounce, tx, path), interleaved with the records' "-=" on the same
+             * array.  The two can meet in one slot (the slot tx*np + path is the dense slot of rx 0,
+             * TX (tx*np+path) / (nb*np), ...), and x + (+0) turns a -0 into +0, so the order is
+             * replayed: the hit list is grouped by TX in ascending order (the launch set is, and the
+             * compaction is stable), and per TX the adds go first, then that TX's records. */
+            /* records of (b, rx): D2H into one of two page-locked staging sets on a copy stream,
+             * so that the copy of block rx+1 runs while the host threads scatter block rx */
+#define FETCH_RX(RX, SET_REC, SET_MASK, I0, I1)                                                      \
+    do {                                                                                             \
+        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
+        const uint64_t i0_ = (I0), n_ = (I1) - (I0), w0_ = (I0) / 64, w1_ = ((I1) + 63) / 64;         \
+        int e_ = 0;                                                                                  \
+        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
+            e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w.d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, w.copy_stream); \
+        if (!e_)                                                                                     \
+            e_ = hrt_hip_d2h_async((SET_MASK) + w0_, (const uint8_t *)w.d_ws + L.off_masks + (((uint64_t)b * nrx + (RX)) * (L.cap / 64) + w0_) * 8, \
+                                   (w1_ - w0_) * 8, w.copy_stream);                                  \
+        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
+    } while (0)
+            /* runs of equal TX in the hit list (at most ntx) */
+            uint64_t nruns = 0;
+            if (H) {
+                if (!w.run_start) {
+                    w.run_start = (uint64_t *)malloc((ntx + 1) * sizeof(uint64_t));
+                    w.run_tx = (uint32_t *)malloc(ntx * sizeof(uint32_t));
+                    if (!w.run_start || !w.run_tx) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+                }
+                uint32_t cur = (uint32_t)(w.ray[0] / n_loc);
+                w.run_start[0] = 0; w.run_tx[0] = cur; nruns = 1;
+                /* run boundaries by bisection on the (ascending) TX of the entries */
+                while (w.run_tx[nruns - 1] + 1u < ntx || 1) {
+                    uint64_t lo_i = w.run_start[nruns - 1], hi_i = H;
+                    const uint32_t t_cur = w.run_tx[nruns - 1];
+                    while (lo_i < hi_i) {   /* first entry with tx > t_cur */
+                        const uint64_t mid = (lo_i + hi_i) / 2;
+                        if ((uint32_t)(w.ray[mid] / n_loc) > t_cur) hi_i = mid; else lo_i = mid + 1;
+                    }
+                    if (lo_i >= H) break;
+                    if (nruns >= ntx) { rc = hrt_fail(HRT_E_HIP, "hit list is not grouped by TX"); goto done; }
+                    w.run_start[nruns] = lo_i;
+                    w.run_tx[nruns] = (uint32_t)(w.ray[lo_i] / n_loc);
+                    ++nruns;
+                }
+                w.run_start[nruns] = H;
+            }
+            /* all rx blocks of this bounce are needed per TX run: with one run (one TX, the common
+             * case) the copy of block rx+1 overlaps the scatter of block rx; with several runs the
+             * blocks are fetched once per run (the reference's order is (tx, path, rx)) */
+            for (uint64_t run = 0; run < nruns; ++run) {
+                const uint64_t r0 = w.run_start[run], r1 = w.run_start[run + 1];
+                const size_t txr = w.run_tx[run];
+                for (uint64_t i = r0; i < r1; ++i) {
+                    const uint64_t p = hrt_shard_global_path(&s, w.ray[i] - txr * n_loc);
                     const float *mv = prob->h_mesh + (size_t)prob->h_tri_mesh[w.tri[i]] * HRT_MESH_FLOATS;
                     const float zero = 0.f;   /* d - d with finite d */
                     float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
-                    scat->freq_shift[p] += z * prob->dop_mult;
+                    scat->freq_shift[txr * np + p] += z * prob->dop_mult;
                 }
-            /* records of (b, rx): D2H into one of two page-locked staging sets on a copy stream,
-             * so that the copy of block rx+1 runs while the host threads scatter block rx */
-#define FETCH_RX(RX, SET_REC, SET_MASK)                                                              \
-    do {                                                                                             \
-        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
-        int e_ = 0;                                                                                  \
-        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
-            e_ = hrt_hip_d2h_async((SET_REC)[k], (const uint8_t *)w.d_ws + rb_ + (uint64_t)k * L.cap * 4, H * 4, w.copy_stream); \
-        if (!e_)                                                                                     \
-            e_ = hrt_hip_d2h_async((SET_MASK), (const uint8_t *)w.d_ws + L.off_masks + ((uint64_t)b * nrx + (RX)) * (L.cap / 64) * 8, \
-                                   (H + 63) / 64 * 8, w.copy_stream);                                \
-        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
-    } while (0)
-            if (H) FETCH_RX(0, w.rec, w.mask);
-            for (size_t rx = 0; rx < nrx && H; ++rx) {
-                float *const *cur_rec = (rx & 1) ? w.rec2 : w.rec;
-                const uint64_t *cur_mask = (rx & 1) ? w.mask2 : w.mask;
-                {
-                    const int e = hrt_hip_stream_sync(w.copy_stream);   /* block rx has landed */
-                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
-                }
-                if (rx + 1 < nrx) {
-                    if (rx & 1) FETCH_RX(rx + 1, w.rec, w.mask);
-                    else FETCH_RX(rx + 1, w.rec2, w.mask2);
-                }
-                {
-                    scatter_ctx sc;
-                    memset(&sc, 0, sizeof sc);
-                    sc.s = &s; sc.ray = w.ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
-                    sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
-                    hrt_parallel_ranges(scatter_range, &sc, H, scatter_threads);
-                    for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st.records_unblocked += sc.unblocked[t];
+                if (run == 0) FETCH_RX(0, w.rec, w.mask, r0, r1);
+                for (size_t rx = 0; rx < nrx; ++rx) {
+                    const size_t slot = (size_t)(run * nrx + rx);
+                    float *const *cur_rec = (slot & 1) ? w.rec2 : w.rec;
+                    const uint64_t *cur_mask = (slot & 1) ? w.mask2 : w.mask;
+                    {
+                        const int e = hrt_hip_stream_sync(w.copy_stream);   /* block rx has landed */
+                        if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
+                    }
+                    if (rx + 1 < nrx || run + 1 < nruns) {   /* next block: rx+1, or rx 0 of the next run */
+                        const size_t nrx_next = (rx + 1 < nrx) ? rx + 1 : 0;
+                        const uint64_t n0_ = (rx + 1 < nrx) ? r0 : w.run_start[run + 1];
+                        const uint64_t n1_ = (rx + 1 < nrx) ? r1 : w.run_start[run + 2];
+                        if (slot & 1) FETCH_RX(nrx_next, w.rec, w.mask, n0_, n1_);
+                        else FETCH_RX(nrx_next, w.rec2, w.mask2, n0_, n1_);
+                    }
+                    {
+                        scatter_ctx sc;
+                        memset(&sc, 0, sizeof sc);
+                        sc.s = &s; sc.ray = w.ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
+                        sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
+                        sc.i_base = r0;
+                        hrt_parallel_ranges(scatter_range, &sc, r1 - r0, scatter_threads);
+                        for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st.records_unblocked += sc.unblocked[t];
+                    }
                 }
             }
 #undef FETCH_RX

@@ -513,6 +513,69 @@ int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order
     return HRT_OK;
 }
 
+/* The same job on the device (hrt_launch_order_kernel): d_order[i] = local ray launched at
+ * position i.  The band of a ray is monotone in its local index, so the host only finds the band
+ * boundaries (bisection: bands x log n evaluations), cuts bands longer than 32768 rays, uploads
+ * the segment table and launches one workgroup per segment.  Blocks until done.  The order is not
+ * the host function's (17 instead of 20 azimuth bits, bands cut at 32768) -- any coherent order
+ * serves; results never depend on it. */
+static uint32_t order_band(const hrt_shard *s, uint64_t i, uint32_t nbands)
+{
+    const float n_f = (float)s->num_paths;
+    const float k = (float)hrt_shard_global_path(s, i) + .5f;
+    const float z = 1.f - 2.f * k / n_f;
+    const double zc = z > 1.f ? 1.0 : (z < -1.f ? -1.0 : (double)z);
+    uint32_t band = (uint32_t)(0.5 * (1.0 - zc) * nbands);
+    return band >= nbands ? nbands - 1 : band;
+}
+
+int hrt_launch_order_device(const hrt_shard *s, uint32_t *d_order, int device, void *stream)
+{
+    if (!s || !d_order || s->count == 0 || s->rank >= s->count || s->num_paths == 0)
+        return hrt_fail(HRT_E_INVALID, "hrt_launch_order_device: bad argument");
+    const uint32_t ch = shard_chunk(s);
+    if (ch % 64u) return hrt_fail(HRT_E_INVALID, "shard chunk %u is not a multiple of 64", ch);
+    const uint64_t n = hrt_shard_num_local(s);
+    if (n == 0 || n > 0xffffffffull) return hrt_fail(HRT_E_INVALID, "hrt_launch_order_device: bad shard");
+    uint32_t nbands = (uint32_t)sqrt((double)n / 128.0);
+    if (nbands < 1) nbands = 1;
+    if (nbands > 4095) nbands = 4095;
+    const uint64_t max_seg = (uint64_t)nbands + n / 32768u + 2;
+    uint32_t *seg = (uint32_t *)malloc((max_seg + 1) * 2 * sizeof(uint32_t));
+    if (!seg) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    uint32_t *seg_start = seg, *seg_band = seg + max_seg + 1;
+    uint64_t nseg = 0, pos = 0;
+    while (pos < n) {
+        const uint32_t b = order_band(s, pos, nbands);
+        uint64_t lo = pos + 1, hi = n;      /* first index of a later band */
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (order_band(s, mid, nbands) > b) hi = mid; else lo = mid + 1;
+        }
+        for (uint64_t q = pos; q < lo; q += 32768u) {
+            seg_start[nseg] = (uint32_t)q;
+            seg_band[nseg] = b;
+            ++nseg;
+        }
+        pos = lo;
+    }
+    seg_start[nseg] = (uint32_t)n;
+    seg_band[nseg] = 0;
+    int rc = HRT_OK, e;
+    void *d_seg = NULL;
+    if ((e = hrt_hip_set_device(device))) rc = hrt_fail_hip(e, "hipSetDevice");
+    if (!rc && (e = hrt_hip_malloc(&d_seg, (nseg + 1) * 8))) rc = hrt_fail_hip(e, "hipMalloc(segments)");
+    if (!rc && (e = hrt_hip_h2d(d_seg, seg_start, (nseg + 1) * 4))) rc = hrt_fail_hip(e, "hipMemcpy H2D");
+    if (!rc && (e = hrt_hip_h2d((uint32_t *)d_seg + nseg + 1, seg_band, (nseg + 1) * 4))) rc = hrt_fail_hip(e, "hipMemcpy H2D");
+    if (!rc && (e = hrt_hip_launch_order((const uint32_t *)d_seg, (const uint32_t *)d_seg + nseg + 1, (uint32_t)nseg,
+                                         s->num_paths, s->rank, s->count, ch, d_order, stream)))
+        rc = hrt_fail_hip(e, "hrt_launch_order_kernel");
+    if (!rc && (e = hrt_hip_stream_sync(stream))) rc = hrt_fail_hip(e, "hipStreamSynchronize");
+    if (d_seg) hrt_hip_free(d_seg);
+    free(seg);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ layout + trace */
 
 int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)

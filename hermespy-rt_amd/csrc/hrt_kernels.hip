@@ -1774,6 +1774,70 @@ __global__ void hrt_launch_dirs_kernel(uint64_t num_paths, uint32_t rank, uint32
     }
 }
 
+// ===================================================================================
+// Coherent launch order on the device (the job of hrt_launch_order_host, problem.c): the launch
+// set is walked in z-bands, serpentine in azimuth, so that 64 consecutive positions are a narrow
+// packet.  On a Fibonacci sphere the polar coordinate is monotone in the path index, so a band is a
+// RANGE of (local) indices: the host cuts the shard into segments -- ranges of at most 32768 rays
+// that do not cross a band boundary, found by bisection -- and one workgroup sorts one segment by
+// azimuth in LDS (bitonic, keys = 17 bits of azimuth | 15 bits of offset in the segment: unique, so
+// the result is deterministic).  Results do not depend on the order (records carry ray ids).
+// ===================================================================================
+#define HRT_ORDER_SEG 32768u
+__global__ __launch_bounds__(1024) void hrt_launch_order_kernel(const uint32_t *seg_start,
+                                                                 const uint32_t *seg_band,
+                                                                 uint64_t num_paths, uint32_t rank,
+                                                                 uint32_t count, uint32_t chunk,
+                                                                 uint32_t *order)
+{
+    extern __shared__ uint32_t okeys[];
+    const uint32_t s0 = seg_start[blockIdx.x], n = seg_start[blockIdx.x + 1] - s0;
+    const bool flip = seg_band[blockIdx.x] & 1u;
+    uint32_t npad = 2u;
+    while (npad < n) npad <<= 1;
+    const float golden = kPi * (1.f + sqrtf(5.f));
+    for (uint32_t k = threadIdx.x; k < npad; k += blockDim.x) {
+        uint32_t key = 0xffffffffu;
+        if (k < n) {
+            const uint64_t i = (uint64_t)s0 + k;
+            const uint64_t p = ((i / chunk) * count + rank) * chunk + i % chunk;
+            const float kf = (float)p + .5f;
+            const double th = (double)(golden * kf) * 0.15915494309189533577;   // turns
+            double fr = th - floor(th);
+            uint32_t az = (uint32_t)(fr * 131072.0);
+            if (az > 131071u) az = 131071u;
+            if (flip) az = 131071u - az;
+            key = (az << 15) | k;
+        }
+        okeys[k] = key;
+    }
+    for (uint32_t size = 2u; size <= npad; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+                const uint32_t a = 2u * t - (t & (stride - 1u)), b2 = a + stride;
+                const bool up = (a & size) == 0u;
+                const uint32_t ka = okeys[a], kb = okeys[b2];
+                if ((ka > kb) == up) { okeys[a] = kb; okeys[b2] = ka; }
+            }
+        }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) order[s0 + k] = s0 + (okeys[k] & 0x7fffu);
+    (void)num_paths;
+}
+
+// launch Doppler term of the scatter records, src/compute_paths.c:494-500: out[p] =
+// dot(tx_vel, d_p) * f/c in the reference's float sequence (no contraction in this file)
+__global__ void hrt_fs0_kernel(const float *dirs, uint64_t n, float vx, float vy, float vz, float mult,
+                               float *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F3 tv = {vx, vy, vz};
+    const F3 d = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+    out[i] = dot3(tv, d) * mult;
+}
+
 // evaluates one of the hrt_libm.h functions (or the incidence-angle acos) over an array: the
 // GPU side of tests/test_gpu_libm.py
 __global__ void hrt_selftest_math_kernel(int fn, const float *in, float *out, uint64_t n)
@@ -1850,6 +1914,10 @@ int hrt_hip_stream_sync(void *stream) { return (int)hipStreamSynchronize((hipStr
 int hrt_hip_d2h_async(void *dst, const void *src, uint64_t bytes, void *stream)
 {
     return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+}
+int hrt_hip_h2d_async(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
 }
 int hrt_hip_stream_create(void **stream)
 {
@@ -1955,6 +2023,32 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
     hipLaunchKernelGGL(hrt_launch_dirs_kernel, dim3((uint32_t)((num_local + 255) / 256)), dim3(256),
                        0, (hipStream_t)stream, num_paths, rank, count, chunk, num_local, d_dirs,
                        d_fix_count, d_fix_list, fix_cap);
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(hrt_fs0_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_dirs, n, tx_vel3[0], tx_vel3[1], tx_vel3[2], mult, d_out);
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_launch_order(const uint32_t *d_seg_start, const uint32_t *d_seg_band, uint32_t num_seg,
+                         uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
+                         uint32_t *d_order, void *stream)
+{
+    if (num_seg == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_launch_order_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(HRT_ORDER_SEG * 4u));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(hrt_launch_order_kernel, dim3(num_seg), dim3(1024), HRT_ORDER_SEG * 4u,
+                       (hipStream_t)stream, d_seg_start, d_seg_band, num_paths, rank, count, chunk, d_order);
     return (int)hipGetLastError();
 }
 

@@ -108,6 +108,11 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream);
+int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream);
+int hrt_hip_launch_order(const uint32_t *d_seg_start, const uint32_t *d_seg_band, uint32_t num_seg,
+                         uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
+                         uint32_t *d_order, void *stream);
+int hrt_hip_h2d_async(void *dst, const void *src, uint64_t bytes, void *stream);
 int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, void *stream);
 #define HRT_STATS_COLS 16
 int hrt_hip_read_stats(unsigned long long *out3xCOLS, int reset);

@@ -87,7 +87,15 @@ class Tracer:
         # coherent launch order: a wave = a narrow ray packet (speed only; results are keyed
         # by ray id)
         self.order_host = None
-        if coherent:
+        order_dev = None
+        if coherent and device_dirs:
+            # ... and the coherent order on the device too (hrt_launch_order_device)
+            with torch.cuda.device(self.device):
+                order_dev = torch.empty(self.num_local, dtype=torch.int32, device=self.device)
+            _lib.check(self.L.hrt_launch_order_device(
+                C.byref(self.shard), C.c_void_p(order_dev.data_ptr()), self.device.index,
+                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "hrt_launch_order_device")
+        elif coherent:
             order = np.empty(self.num_local, np.uint32)
             _lib.check(self.L.hrt_launch_order_host(
                 C.byref(self.shard), dirs.ctypes.data_as(C.POINTER(C.c_float)) if dirs is not None else None,
@@ -96,8 +104,8 @@ class Tracer:
         with torch.cuda.device(self.device):
             if dirs is not None:
                 self.dirs = torch.from_numpy(dirs).to(self.device)
-            self.order = (torch.from_numpy(self.order_host.view(np.int32)).to(self.device)
-                          if coherent else None)
+            self.order = order_dev if order_dev is not None else (
+                torch.from_numpy(self.order_host.view(np.int32)).to(self.device) if coherent else None)
             # the launch set is traced again and again: permute the direction table into launch
             # order ONCE, so the launch kernels read contiguous runs (HRT_DIRS_IN_LAUNCH_ORDER)
             self.flags = 0

@@ -17,7 +17,7 @@ EXPORTED = (
     "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_problem_tri_order", "hrt_shard_num_local",
-    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_layout_query", "hrt_trace",
+    "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_launch_order_device", "hrt_layout_query", "hrt_trace",
     "hrt_work_from_counts", "hrt_timer_create", "hrt_timer_destroy", "hrt_trace_timed",
     "hrt_trace_flags",
     "hrt_timer_read", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
@@ -81,7 +81,7 @@ def load():
         raise HrtError("%s not found: build it first (make -C hermespy-rt_amd). There is no "
                        "CPU fallback." % LIB_PATH)
     L = C.CDLL(LIB_PATH)
-    abi.bind_reference_abi(L)
+    abi.bind_c_abi(L)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     V3 = C.POINTER(abi.Vec3)
     f32p = C.POINTER(C.c_float)
@@ -119,6 +119,8 @@ def load():
     L.hrt_launch_order_host.restype = C.c_int
     L.hrt_launch_dirs_device.argtypes = [C.POINTER(Shard), vp, C.c_int, vp, C.POINTER(u64)]
     L.hrt_launch_dirs_device.restype = C.c_int
+    L.hrt_launch_order_device.argtypes = [C.POINTER(Shard), vp, C.c_int, vp]
+    L.hrt_launch_order_device.restype = C.c_int
     L.hrt_trace.argtypes = [vp, C.POINTER(Shard), vp, vp, vp, u64, vp, C.POINTER(KernelTimes)]
     L.hrt_trace.restype = C.c_int
     L.hrt_timer_create.argtypes = [u32, C.POINTER(vp)]

@@ -92,6 +92,12 @@ int hrt_launch_dirs_device(const hrt_shard *s, float *d_dirs, int device, void *
  * speed does. */
 int hrt_launch_order_host(const hrt_shard *s, const float *dirs, uint32_t *order_out);
 
+/* The same kind of order computed ON THE DEVICE into d_order (device [num_local] u32): bands are
+ * ranges of the local index on a Fibonacci sphere, so one workgroup sorts one band segment by
+ * azimuth in LDS.  Not the same permutation as hrt_launch_order_host (coarser azimuth keys), equally
+ * coherent; what compute_paths() uses.  Blocks until done. */
+int hrt_launch_order_device(const hrt_shard *s, uint32_t *d_order, int device, void *stream);
+
 /* ---- workspace layout ----
  * cap = num_tx * num_local rounded up to 256 entries.  Every array below holds `cap`
  * elements of 4 bytes unless noted, so a field is a contiguous, coalesced run.

@@ -58,7 +58,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # HRT_ORACLE_LIB: another build of the same source (the sanitizer build, `make -C oracle asan`)
+        _lib = C.CDLL(os.environ.get("HRT_ORACLE_LIB") or build())
         _lib.hrt_oracle_compute_paths.restype = C.c_int
         _lib.hrt_oracle_compute_paths.argtypes = [
             C.POINTER(_Scene), _f32p, _f32p, _f32p, _f32p, C.c_float,

@@ -1,30 +1,12 @@
-"""Named workloads: BASELINE.json configs with the synthetic endpoints fixed in SURVEY.md 8(d).
+"""Named workloads: BASELINE.json configs with the synthetic endpoints fixed in SURVEY.md 8(d)
+(defined in hermespy_rt_amd.workloads, which bench.py uses too) plus test-only cases.
 `small(cfg, n)` keeps everything but the ray count (parity-test sizes)."""
 import os
 
+from hermespy_rt_amd.workloads import (C1, C2, C3, C3_DOPPLER, C3_RX, C4, C4_DOPPLER, C5, SC, Z,  # noqa: F401
+                                       cfg)
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SC = os.path.join(REPO, "scenes")
-Z = [0.0, 0.0, 0.0]
-
-
-def cfg(scene, rx, tx, f, np_, nb, rx_vel=None, tx_vel=None):
-    return dict(scene_path=os.path.join(SC, scene), rx_pos=rx, tx_pos=tx,
-                rx_vel=rx_vel or [Z] * len(rx), tx_vel=tx_vel or [Z] * len(tx),
-                f_ghz=f, num_paths=np_, num_bounces=nb)
-
-
-C1 = cfg("box.hrt", [[2, 1, 1.5]], [[0, 0, 2.5]], 3.0, 10000, 1)
-C2 = cfg("simple_reflector.hrt", [[0, 0, .15]], [[0, 0, .151]], 3.0, 1000000, 2)
-C3_RX = [[-10, 1.5, 1.5], [10, -1.5, 1.5], [35, 0, 1.5], [50, 2, 3]]
-C3 = cfg("simple_street_canyon_with_cars.hrt", C3_RX, [[-40, 0, 10]], 3.5, 4000000, 4)
-C3_DOPPLER = cfg("simple_street_canyon_with_cars.hrt", C3_RX, [[-40, 0, 10]], 3.5, 4000000, 4,
-                 rx_vel=[[1, 2, 3]] * 4, tx_vel=[[10, 0, 0]])
-C4 = cfg("2cars.hrt", [[-2, 0, 1.5], [2, 0, 1.5]], [[0, -20, 3], [0, 20, 3]], 70.0, 8000000, 6)
-C4_DOPPLER = cfg("2cars.hrt", [[-2, 0, 1.5], [2, 0, 1.5]], [[0, -20, 3], [0, 20, 3]], 70.0,
-                 8000000, 6, rx_vel=[[1, 0, 0], [0, 1, 0]], tx_vel=[[3, 1, 0], [0, -2, 1]])
-C5 = cfg("simple_street_canyon_with_cars.hrt",
-         [[x, y, 1.5] for x in (-50, -25, 0, 25) for y in (-1.5, 1.5)],
-         [[x, y, 10] for x in (-60, -20, 20, 60) for y in (-2, 2)], 3.5, 8000000, 8)
 # the reference's own smoke test (test/test.py:8-17)
 TEST_PY = cfg("simple_reflector.hrt", [[0, 0, .15]], [[0, 0, .151]], 3.0, 10000, 3)
 # tx == rx (coincident LoS branch), test/test.c:22-23

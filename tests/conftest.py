@@ -40,4 +40,5 @@ def ref_lib():
     p = os.path.join(REPO, "oracle", "_ref", "libhrt_ref.so")
     if not os.path.exists(p):
         pytest.skip("oracle/_ref/libhrt_ref.so not built (needs /root/reference)")
-    return abi.bind_reference_abi(ctypes.CDLL(p))
+    from . import refabi
+    return refabi.load()

@@ -89,7 +89,8 @@ def load_ref():
     p = os.path.join(REPO, "oracle", "_ref", "libhrt_ref.so")
     if not os.path.exists(p):
         sys.exit("oracle/_ref/libhrt_ref.so missing: run `make -C oracle ref` where /root/reference is mounted")
-    return abi.bind_reference_abi(ctypes.CDLL(p))
+    from tests import refabi
+    return refabi.load()
 
 
 def flat(res):

@@ -2,6 +2,7 @@
 
 Tolerances (north_star): bit-exact for everything that is integer/index/geometry work --
 written-slot sets, hit indices, counts, rays, active masks, delays (tau), directions -- and
+(freq_shift included, down to the sign of zero: the reference's `+= 0` quirk Q10 is replayed) and
 1e-5 relative for the complex amplitudes, which go through sin/cos/exp/acos (device libm vs
 glibc).  'Relative' for a complex amplitude is taken on the complex value: |a - a_ref| <=
 1e-5 * |a_ref| (+ a tiny absolute floor for exact zeros), the standard for phasors; the
@@ -55,7 +56,7 @@ def amp_error(re, im, re_ref, im_ref, sentinel_mask=None):
     return float(np.max(err[~zero] / mag[~zero])) if (~zero).any() else 0.0
 
 
-def compare_dense(got, ref, amp_rtol=AMP_RTOL, check_rays=True, exact_freq_shift=False):
+def compare_dense(got, ref, amp_rtol=AMP_RTOL, check_rays=True, exact_freq_shift=True):
     """got/ref: dicts as returned by abi.run_compute_paths / oracle.compute_paths."""
     from hermespy_rt_amd.abi import written
     stats = {}
