@@ -2,34 +2,47 @@
 """bench.py -- the compute_paths hot path on N MI355X GPUs (one process per GPU).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over the whole launch set of the workload: state init
-from the (HBM-resident) launch directions, LoS pass, and num_bounces+1 launches of the
-trace / shade / compaction kernels.  Inputs (scene, endpoints, launch directions) are
-resident in HBM before the timed region; outputs (compact path records) stay in HBM, sharded
-over the ranks exactly as at N = 1 -- rays are independent, the path itself has no exchange
-step.  The collection of every rank's records on rank 0 (RCCL gather over xGMI,
-hermespy_rt_amd.sharding) is measured right after the timed region and reported beside the
-metric ("gather": ms, bytes, GB/s, and the throughput if it were serialised into every step);
-`--gather-in-step` puts it inside the timed step instead.  Why it is not the default: one
-MI355X produces ~385 GB/s of path records on this workload, the root of a gather can ingest
-at most 7 x 153 GB/s over xGMI, so a gather-to-one-GPU of everything is bandwidth-bound at
-~2.8 producer GPUs whatever the kernels do.
+With --gpus N > 1 and no torch.distributed environment, bench.py launches its own N rank
+processes (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1,
+started BEFORE this process touches the GPU) and passes their output through; under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE set) it is a rank.
 
-Workload at N = 1 is BASELINE.json configs[2] (the config its metric and target are quoted
-on): simple_street_canyon_with_cars.hrt, 1 TX + 4 RX, 4M rays, 4 bounces, 3.5 GHz, endpoints
-as fixed in SURVEY.md 8(d).  Scaling is WEAK: N GPUs trace an N-times denser Fibonacci
-sphere (N x 4M rays), ray-sharded round-robin in 4096-path granules.
+A "step" is one pass of the hot path over the whole launch set of the workload: state init from
+the (HBM-resident) launch directions, LoS pass, and num_bounces+1 launches of the trace / shade
+kernels.  SCOPE of `value`: inputs (scene, endpoints, launch directions in launch order) are
+resident in HBM before the timed region and outputs (compact path records) stay in HBM, sharded
+over the ranks -- it is the steady-state kernel rate.  What a caller of the drop-in pays on top is
+reported beside it, measured in the same process right after the timed region (N = 1):
 
-Prints ONE JSON line on rank 0.  metric = resolved propagation paths per second (scatter
-records written, blocked ones included, + LoS entries), whole job; ray-triangle tests/s of
-the brute-force algorithm is reported beside it.
+    step_incl_launch_ms   the step with the launch directions and launch order generated inside it
+                          (they are part of compute_paths in the reference, src/compute_paths.c:442-456)
+    end_to_end            hrt_compute_paths_ex on host arrays, cold and warm, with its phase split
+                          (setup, launch tables, device, D2H + dense scatter) -- the PCIe-inclusive figure
+    sustained             the same step repeated for >= 1 s of GPU time (the 20-step timed region is
+                          35 ms; this is the region a utilisation sampler can see)
+
+N > 1 (weak scaling: N GPUs trace an N-times denser Fibonacci sphere, ray-sharded round-robin in
+4096-path granules): `value` has no exchange step in it (rays are independent); the collection of
+the records is measured right after and reported as first-class numbers:
+
+    value_with_gather     every rank's packed records -> rank 0 over RCCL (xGMI), serialised into the step
+    value_with_d2h        every rank copies its own packed records to its host over its own PCIe link
+                          (--collect d2h / both; no root)
+
+Prints ONE JSON line on rank 0.  metric = resolved propagation paths per second (scatter records
+written, blocked ones included, + LoS entries), whole job; ray-triangle tests/s of the brute-force
+algorithm and the non-zero (unblocked) paths/s are reported beside it.  A hang in a collective
+ends the run with a NON-ZERO exit code after the line (with `gather_error`) has been printed.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -39,17 +52,18 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
-
-def workloads():
-    from tests import configs as K
-    return {"c1": K.C1, "c2": K.C2, "c3": K.C3, "c4": K.C4, "c5": K.C5,
-            "c3_doppler": K.C3_DOPPLER}
+_print_lock = threading.Lock()
+_printed = False
 
 
-def describe(c):
-    return "%s, %d TX + %d RX, %d rays/TX, %d bounces, %.1f GHz" % (
-        os.path.basename(c["scene_path"]), len(c["tx_pos"]), len(c["rx_pos"]), c["num_paths"],
-        c["num_bounces"], c["f_ghz"])
+def emit(out):
+    """rank 0's one JSON line, printed exactly once (the watchdogs race the main thread)"""
+    global _printed
+    with _print_lock:
+        if _printed:
+            return
+        _printed = True
+        print(json.dumps(out), flush=True)
 
 
 def algorithmic_bytes(live, nrx, n_launch_rays, rec_unblocked, rec_blocked):
@@ -65,46 +79,73 @@ def algorithmic_bytes(live, nrx, n_launch_rays, rec_unblocked, rec_blocked):
 
 def cpu_baseline(c, budget_s=20.0):
     """The reference itself (oracle/_ref, built in place from the reference sources; it is
-    single-threaded) on a bounded sample of the workload, else our CPU port of it."""
-    import ctypes
-    from oracle import oracle
+    single-threaded) on a bounded sample of the workload, and our CPU port of it on all cores."""
+    from oracle import oracle                      # checker: only this leg of bench.py uses it
+    from tests import refabi
+    from hermespy_rt_amd import abi, workloads as W
     out = {}
-    ref_so = os.path.join(REPO, "oracle", "_ref", "libhrt_ref.so")
-    # the single-threaded reference does 1.2e8 (this container) to 2.9e8 (GPU box host) tests/s
+    # the single-threaded reference does 1.2e8 (build container) to 2.9e8 (GPU box host) tests/s
     # on C3; size the sample for about budget_s at 2e8: a sparser Fibonacci sphere of the same
     # scene/endpoints (10-15 s on the GPU box, well under a minute anywhere)
     T = len(oracle.flatten(oracle.read_hrt(c["scene_path"]))["tri_vtx"])
     per_ray = T * (1 + len(c["rx_pos"])) * c["num_bounces"] * len(c["tx_pos"]) * 0.5
     n_sample = int(min(c["num_paths"], max(10000, budget_s * 2.0e8 / max(per_ray, 1.0))))
     sc = dict(c, num_paths=n_sample)
-    from tests import configs as K
-    if os.path.exists(ref_so):
-        from hermespy_rt_amd import abi
-        lib = abi.bind_reference_abi(ctypes.CDLL(ref_so))
+    ref_dt = None
+    if refabi.available():
+        lib = refabi.load()
         t0 = time.time()
-        r = abi.run_compute_paths(lib, *K.args(sc))
-        dt = time.time() - t0
+        r = abi.run_compute_paths(lib, *W.args(sc))
+        ref_dt = time.time() - t0
         recs = int(abi.written(r["scat"]["a_te_re"]).sum()) + len(c["rx_pos"]) * len(c["tx_pos"])
-        out = dict(value=recs / dt, unit="paths/s", cores=1, kind="reference",
+        out = dict(value=recs / ref_dt, unit="paths/s", cores=1, kind="reference", seconds=ref_dt,
                    sample="%s (num_paths %d of %d), reference src/compute_paths.c built "
-                          "gcc -O3 -ffp-contract=off, %.1f s" % (describe(sc), n_sample, c["num_paths"], dt))
+                          "gcc -O3 -ffp-contract=off, %.1f s" % (W.describe(sc), n_sample, c["num_paths"], ref_dt))
         del r
-    # our port, all host cores (an upper bound for an embarrassingly parallel CPU version)
+    # our port, all host cores (an upper bound for an embarrassingly parallel CPU version);
     # the box's CPU share for one GPU is 16 threads
     nthr = min(16, oracle.lib().hrt_oracle_max_threads(), len(os.sched_getaffinity(0)))
     t0 = time.time()
-    o = oracle.compute_paths(*K.args(sc), num_threads=nthr)
+    o = oracle.compute_paths(*W.args(sc), num_threads=nthr)
     dt = time.time() - t0
     recs = int(o["extras"]["live"][1:].sum()) * len(c["rx_pos"]) + len(c["rx_pos"]) * len(c["tx_pos"])
-    port = dict(value=recs / dt, unit="paths/s", cores=nthr, kind="port",
+    port = dict(value=recs / dt, unit="paths/s", cores=nthr, kind="port", seconds=dt,
                 tests_per_s=o["extras"]["tests"] / dt,
                 sample="%s (num_paths %d of %d), oracle/hrt_oracle.c OpenMP, %.1f s" % (
-                    describe(sc), n_sample, c["num_paths"], dt))
+                    W.describe(sc), n_sample, c["num_paths"], dt))
     if out:
-        out["tests_per_s"] = o["extras"]["tests"] / max(1e-9, float(out["sample"].split(",")[-1].split()[0]))
+        out["tests_per_s"] = o["extras"]["tests"] / max(1e-9, ref_dt)
         out["port_all_cores"] = port
         return out
     return port
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks ourselves.  This
+    process has not touched the GPU (no HIP call, no torch.cuda query), so starting children is safe;
+    it never replaces itself with another program."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dropin_once(c, lib_, abi, W):
+    st = lib_.Stats()
+    t0 = time.time()
+    abi.run_compute_paths(lib_.load(), *W.args(c), with_rays=False, stats=st)
+    wall = time.time() - t0
+    paths = int(st.records) + len(c["rx_pos"]) * len(c["tx_pos"])
+    host_bytes = 4 * 9 * len(c["rx_pos"]) * len(c["tx_pos"]) * c["num_bounces"] * c["num_paths"]
+    return dict(t_total_s=st.t_total_s, t_setup_s=st.t_setup_s, t_launch_tables_s=st.t_launch_dirs_s,
+                t_device_s=st.t_device_s, t_readback_and_dense_scatter_s=st.t_readback_s,
+                wall_incl_python_alloc_s=wall, paths_per_s=paths / st.t_total_s,
+                tests_per_s=int(st.tests) / st.t_total_s, records=int(st.records),
+                records_unblocked=int(st.records_unblocked), dense_host_bytes=host_bytes)
 
 
 def main():
@@ -115,40 +156,39 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--gather-in-step", action="store_true",
                     help="N > 1: run the RCCL gather of all records to rank 0 inside every timed step")
+    ap.add_argument("--collect", choices=("gather", "d2h", "both", "none"), default="both",
+                    help="N > 1: which collection step(s) to measure after the timed region")
     ap.add_argument("--time-every", type=int, default=4,
                     help="record the per-kernel HIP events on every n-th timed step (default 4)")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: do not measure the gather at all")
+    ap.add_argument("--no-gather", action="store_true", help="same as --collect none")
     ap.add_argument("--gather-timeout", type=float, default=120.0,
-                    help="N > 1: give up on the gather measurement after this many seconds")
+                    help="N > 1: give up on a collection measurement after this many seconds (exit code 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="N = 1: skip the drop-in / launch-inclusive / sustained measurements")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--sustain-s", type=float, default=1.2, help="GPU seconds of the sustained region")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch hrt_selftest_math_kernel over 32M floats (known traffic: "
                          "128 MiB read + 128 MiB written, 4 B/lane) to calibrate PMC byte counters")
     ap.add_argument("--dropin", action="store_true",
-                    help="instead of the HBM-resident bench: time the host-array drop-in C ABI "
-                         "(hrt_compute_paths_ex: launch dirs on the host, H2D, trace, D2H, dense "
-                         "scatter) once and print its phase times (the PCIe-inclusive figure)")
+                    help="only time the host-array drop-in C ABI (hrt_compute_paths_ex), cold and warm")
     args = ap.parse_args()
+    if args.no_gather:
+        args.collect = "none"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    from hermespy_rt_amd import workloads as W
     if args.dropin:
         import torch  # noqa: F401
         from hermespy_rt_amd import abi, lib
-        from tests import configs as K
-        c = workloads()[args.workload]
-        st = lib.Stats()
-        t0 = time.time()
-        abi.run_compute_paths(lib.load(), *K.args(c), with_rays=False, stats=st)
-        wall = time.time() - t0
-        nb = c["num_bounces"]
-        paths = int(st.records) + len(c["rx_pos"]) * len(c["tx_pos"])
-        print(json.dumps(dict(
-            mode="dropin (host arrays in/out, PCIe inclusive)", workload=describe(c),
-            t_total_s=st.t_total_s, t_setup_s=st.t_setup_s, t_launch_dirs_host_s=st.t_launch_dirs_s,
-            t_device_incl_h2d_s=st.t_device_s, t_readback_and_dense_scatter_s=st.t_readback_s,
-            wall_incl_python_alloc_s=wall, paths_per_s=paths / st.t_total_s,
-            tests_per_s=int(st.tests) / st.t_total_s, live=[int(st.live[i]) for i in range(nb + 1)],
-            records=int(st.records), records_unblocked=int(st.records_unblocked))))
+        c = W.WORKLOADS[args.workload]
+        cold = dropin_once(c, lib, abi, W)
+        warm = dropin_once(c, lib, abi, W)
+        print(json.dumps(dict(mode="dropin (host arrays in/out, PCIe inclusive)", workload=W.describe(c),
+                              cold=cold, warm=warm)))
         return
 
     import torch
@@ -157,11 +197,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
     # HRT_BENCH_REHEARSE=1: N ranks share GPU 0 and talk over gloo -- a functional rehearsal of
@@ -171,8 +207,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -183,22 +221,22 @@ def main():
         if world == 1:
             return t
         if rehearse:
-            c = t.cpu()
-            dist.all_reduce(c, op=op)
-            return c.to(t.device)
+            c_ = t.cpu()
+            dist.all_reduce(c_, op=op)
+            return c_.to(t.device)
         dist.all_reduce(t, op=op)
         return t
 
     from hermespy_rt_amd.device import Tracer
     from hermespy_rt_amd import sharding
 
-    base = workloads()[args.workload]
+    base = W.WORKLOADS[args.workload]
     c = dict(base, num_paths=base["num_paths"] * world)   # weak scaling: denser sphere
     tr = Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"], c["f_ghz"],
                 c["num_paths"], c["num_bounces"], rank=rank, world=world)
     gather = None
     gather_err = None
-    if world > 1 and not args.no_gather:
+    if world > 1 and args.collect in ("gather", "both") or (world > 1 and args.gather_in_step):
         try:
             gather = sharding.RecordGather(tr)
         except Exception as e:   # never let the collection step take the metric down
@@ -283,13 +321,17 @@ def main():
     ach = B_local / (kern_ms_step * 1e-3) / 1e9
     tests_local = w["tests"]
     # HBM bytes per launch from PMC counters: collected by profiles/collect_pmc.sh (separate
-    # rocprofv3 passes) for exactly this workload at N = 1, committed in profiles/
-    traffic, traffic_src = None, None
+    # rocprofv3 passes) for exactly this workload at N = 1, committed in profiles/.  The JSON carries
+    # the hash of the kernel source it was measured on: `traffic_stale` says whether that is still
+    # the source of this run.
+    kern_sha = hashlib.sha256(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", "hrt_kernels.hip"), "rb").read()).hexdigest()[:16]
+    traffic, traffic_src, traffic_stale = None, None, None
     try:
         pj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
         if world == 1 and args.workload in pj:
             traffic = pj[args.workload]["hbm_bytes_per_launch_avg"]
             traffic_src = pj[args.workload]["source"]
+            traffic_stale = pj[args.workload].get("kernels_sha16") != kern_sha
     except (OSError, ValueError, KeyError):
         pass
     # VALU issue utilisation of the two kernels (SURVEY 8d asks for the VALU fraction next to the
@@ -298,12 +340,14 @@ def main():
     try:
         vj = json.load(open(os.path.join(REPO, "profiles", "pmc_valu.json")))
         if world == 1 and args.workload in vj:
-            valu = dict(vj[args.workload]["kernels"], source=vj[args.workload]["source"])
+            valu = dict(vj[args.workload]["kernels"], source=vj[args.workload]["source"],
+                        stale=vj[args.workload].get("kernels_sha16") != kern_sha)
     except (OSError, ValueError, KeyError):
         pass
     roofline = dict(bound="hbm", kernel="hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)",
                     achieved=ach, peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                    traffic_stale=traffic_stale, kernels_sha16=kern_sha,
                     algorithmic_bytes_per_launch=B_local / n_launch,
                     avg_launch_ms=kern_ms_step / n_launch, launches_per_step=n_launch,
                     steps_with_kernel_events=int(bm.shape[0]),
@@ -312,7 +356,7 @@ def main():
                     shade_kernel_ms=[float(x) for x in sm.mean(axis=0)],
                     kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
                     compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
-                    trace_variant=os.environ.get("HRT_TRACE_VARIANT", "default(2: packet culling)"),
+                    trace_variant=os.environ.get("HRT_TRACE_VARIANT", "auto (flat packet culling; trees on big sparse tables)"),
                     valu=valu,
                     note="VALU-bound intersection work, not HBM-bound: see DESIGN.md section 6")
 
@@ -325,85 +369,161 @@ def main():
             kstats = [[int(arr[k * 16 + j]) for j in range(8)] for k in range(3)]
     except Exception:
         pass
+    out = None
     if rank == 0:
         out = dict(
             metric="resolved propagation paths/sec", value=paths * args.steps / dt,
             unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload=describe(c), name=args.workload,
+            config=dict(workload=W.describe(c), name=args.workload,
                         parallelism="ray-sharded x%d, round-robin 4096-path granules%s" % (
                             world, ", RCCL gather to rank 0 inside the step" if in_step else ""),
-                        rays_total=c["num_paths"] * ntx),
+                        rays_total=c["num_paths"] * ntx,
+                        scope="steady-state kernels: scene, endpoints and launch directions resident in HBM, "
+                              "compact records left in HBM; launch-table generation, H2D/D2H and the dense "
+                              "scatter are NOT in `value` -- see step_incl_launch_ms and end_to_end"),
             ray_tri_tests_per_sec=tests * args.steps / dt,
             nonzero_paths_per_sec=(unblk + nrx * ntx) * args.steps / dt,
             work=dict(live=live, records=records, records_unblocked=unblk, tests=tests),
             roofline=roofline)
         if kstats:
-            out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact", "heavy_packets", "heavy_candidates"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
-    else:
-        out = None
+            out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact", "c6", "c7"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
 
-    # ---- the collection step, measured on its own (N > 1), LAST and under a watchdog: the
-    # metric above is complete before the first collective of the gather is issued, and if the
-    # gather hangs (it cannot be rehearsed over real xGMI links on a one-GPU box) every rank
-    # leaves after `--gather-timeout` seconds and rank 0 still prints the line ----
-    gather_info = None
-    if gather is not None and not in_step:
-        import threading
+    # ---- N = 1: what the steady-state number leaves out, measured in this process ----
+    if world == 1 and not args.no_end_to_end:
+        try:
+            # (a) sustained: the same step for >= sustain_s of GPU time
+            n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-6)) + 1)
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for _ in range(n_sus):
+                tr.trace()
+            torch.cuda.synchronize()
+            s_dt = time.perf_counter() - s0
+            out["sustained"] = dict(steps=n_sus, seconds=s_dt, ms_per_step=s_dt / n_sus * 1e3,
+                                    paths_per_s=paths * n_sus / s_dt)
+            # (b) the step with the launch tables generated inside it (device generators)
+            n_li = max(3, min(args.steps, 20))
+            tr.regen_launch_tables()
+            torch.cuda.synchronize()
+            l0 = time.perf_counter()
+            for _ in range(n_li):
+                tr.regen_launch_tables()
+                tr.trace()
+            torch.cuda.synchronize()
+            l_dt = (time.perf_counter() - l0) / n_li
+            out["step_incl_launch_ms"] = l_dt * 1e3
+            out["step_incl_launch"] = dict(ms=l_dt * 1e3, paths_per_s=paths / l_dt, steps=n_li,
+                                           what="hrt_launch_dirs_device + hrt_launch_order_device + permutation "
+                                                "of the direction table into launch order + the step")
+            # (c) the drop-in ABI end to end (host arrays, PCIe inclusive): first call and second call
+            from hermespy_rt_amd import abi, lib as _lib
+            tr.close()
+            del tr
+            torch.cuda.empty_cache()
+            cold = dropin_once(base, _lib, abi, W)
+            warm = dropin_once(base, _lib, abi, W)
+            out["end_to_end"] = dict(
+                what="hrt_compute_paths_ex (the drop-in C ABI behind compute_paths): host arrays in, the "
+                     "reference's dense arrays out; cold = first call in this process after the bench "
+                     "(HIP already initialised), warm = second call",
+                cold=cold, warm=warm)
+        except Exception as e:
+            out["end_to_end_error"] = repr(e)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(base, args.cpu_budget_s)
 
+    # ---- N > 1: the collection step, measured on its own, LAST and under a watchdog: the metric
+    # above is complete before the first collective is issued; if a collective hangs every rank
+    # leaves after `--gather-timeout` seconds, rank 0 prints the line with `gather_error`, and the
+    # exit code is 3 ----
+    def watchdog(what):
         def bail():
             if rank == 0:
-                out["gather_error"] = "timeout after %.0f s" % args.gather_timeout
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+                out["gather_error"] = "%s: timeout after %.0f s" % (what, args.gather_timeout)
+                emit(out)
+            os._exit(3)
+        t = threading.Timer(args.gather_timeout, bail)
+        t.daemon = True
+        t.start()
+        return t
 
-        dog = threading.Timer(args.gather_timeout, bail)
-        dog.daemon = True
-        dog.start()
-        try:
-            gather.run()                      # warm-up: allocates the receive buffers
-            torch.cuda.synchronize()
-            dist.barrier()
-            g0 = time.perf_counter()
-            n_g = 3
-            for _ in range(n_g):
-                gather.run()
-            torch.cuda.synchronize()
-            dist.barrier()
-            g_dt = xreduce(torch.tensor([(time.perf_counter() - g0) / n_g], dtype=torch.float64,
-                                        device=dev), dist.ReduceOp.MAX)
-            words = sum(sharding.export_words(gather.counts_all[r], tr.nb, tr.nrx)
-                        for r in range(world) if r != 0) if rank == 0 else 0
-            gather_info = dict(ms=float(g_dt.item()) * 1e3, bytes_into_root=int(words) * 4)
-        except Exception as e:
-            gather_err = "run: %r" % (e,)
-        dog.cancel()
+    if world > 1:
+        if rank == 0:
+            out["collect"] = dict(backend=backend, n_ranks_seen_by_backend=dist.get_world_size(),
+                                  n_ranks_seen_by_rccl=(dist.get_world_size() if backend == "nccl" else 0))
+        if gather is not None and not in_step:
+            dog = watchdog("gather")
+            try:
+                if os.environ.get("HRT_BENCH_FORCE_HANG") == "1":   # test hook: a collective that never returns
+                    time.sleep(args.gather_timeout + 60)
+                gather.run()                      # warm-up: allocates the receive buffers
+                torch.cuda.synchronize()
+                dist.barrier()
+                g0 = time.perf_counter()
+                n_g = 3
+                for _ in range(n_g):
+                    gather.run()
+                torch.cuda.synchronize()
+                dist.barrier()
+                g_dt = xreduce(torch.tensor([(time.perf_counter() - g0) / n_g], dtype=torch.float64,
+                                            device=dev), dist.ReduceOp.MAX)
+                if rank == 0:
+                    words = sum(sharding.export_words(gather.counts_all[r], tr.nb, tr.nrx)
+                                for r in range(world) if r != 0)
+                    gms = float(g_dt.item()) * 1e3
+                    out["collect"]["gather"] = dict(
+                        ms=gms, bytes_into_root=int(words) * 4, GBps_into_root=int(words) * 4 / max(gms, 1e-9) / 1e6,
+                        what="all ranks' packed path records -> rank 0, grouped send/recv, measured after the "
+                             "timed region (3 runs, max over ranks)")
+                    out["value_with_gather"] = paths / (dt / args.steps + gms * 1e-3)
+            except Exception as e:
+                gather_err = "run: %r" % (e,)
+            dog.cancel()
+        if args.collect in ("d2h", "both"):
+            dog = watchdog("d2h")
+            try:
+                cnt = tr.counts()
+                pk = sharding.pack_export(tr, cnt)
+                host = torch.empty(pk.numel(), dtype=torch.int32, pin_memory=True)
+                host.copy_(pk, non_blocking=True)
+                torch.cuda.synchronize()
+                dist.barrier()
+                h0 = time.perf_counter()
+                n_h = 3
+                for _ in range(n_h):
+                    pk = sharding.pack_export(tr, cnt, pk)
+                    host.copy_(pk, non_blocking=True)
+                torch.cuda.synchronize()
+                dist.barrier()
+                h_dt = xreduce(torch.tensor([(time.perf_counter() - h0) / n_h], dtype=torch.float64,
+                                            device=dev), dist.ReduceOp.MAX)
+                nbytes = xreduce(torch.tensor([float(pk.numel() * 4)], dtype=torch.float64, device=dev),
+                                 dist.ReduceOp.SUM)
+                if rank == 0:
+                    hms = float(h_dt.item()) * 1e3
+                    out["collect"]["d2h"] = dict(
+                        ms=hms, bytes_all_ranks=int(nbytes.item()), GBps_all_ranks=float(nbytes.item()) / max(hms, 1e-9) / 1e6,
+                        what="every rank packs its records (device) and copies them to page-locked host "
+                             "memory over its own PCIe link; no root (3 runs, max over ranks)")
+                    out["value_with_d2h"] = paths / (dt / args.steps + hms * 1e-3)
+            except Exception as e:
+                gather_err = (gather_err + "; " if gather_err else "") + "d2h: %r" % (e,)
+            dog.cancel()
     if rank == 0:
-        if gather_info:
-            gms = gather_info["ms"]
-            gather_info["GBps_into_root"] = gather_info["bytes_into_root"] / max(gms, 1e-9) / 1e6
-            gather_info["value_if_serialised_into_step"] = paths / (dt / args.steps + gms * 1e-3)
-            gather_info["what"] = ("all ranks' packed path records -> rank 0, RCCL grouped send/recv over "
-                                   "xGMI, measured after the timed region (3 runs, max over ranks)")
-            out["gather"] = gather_info
         if gather_err:
             out["gather_error"] = gather_err
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
-        dog2 = None
+        dog2 = threading.Timer(60.0, lambda: os._exit(4))   # the line is out; a hung teardown is still a failure
+        dog2.daemon = True
+        dog2.start()
         try:
-            import threading
-            dog2 = threading.Timer(60.0, lambda: os._exit(0))   # the line is out: never hang on teardown
-            dog2.daemon = True
-            dog2.start()
             dist.barrier()
             dist.destroy_process_group()
         finally:
-            if dog2 is not None:
-                dog2.cancel()
+            dog2.cancel()
 
 
 if __name__ == "__main__":

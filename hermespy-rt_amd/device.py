@@ -154,6 +154,23 @@ class Tracer:
             return self.last_times
         return None
 
+    def regen_launch_tables(self):
+        """Generate this shard's launch directions and coherent launch order again, ON THE DEVICE
+        (hrt_launch_dirs_device, hrt_launch_order_device), and permute the direction table into launch
+        order -- what a caller pays per call when the launch set is not kept (bench.py:
+        step_incl_launch_ms).  The directions are bit-identical to the host's; results do not depend
+        on the order."""
+        torch = self.torch
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.order is None:
+            raise _lib.HrtError("regen_launch_tables needs a coherent Tracer")
+        _lib.check(self.L.hrt_launch_dirs_device(C.byref(self.shard), C.c_void_p(self.dirs.data_ptr()),
+                                                 self.device.index, stream, None), "hrt_launch_dirs_device")
+        _lib.check(self.L.hrt_launch_order_device(C.byref(self.shard), C.c_void_p(self.order.data_ptr()),
+                                                  self.device.index, stream), "hrt_launch_order_device")
+        self.dirs_launch = self.dirs[self.order.to(torch.int64) & 0xFFFFFFFF].contiguous()
+        self.flags = _lib.DIRS_IN_LAUNCH_ORDER
+
     # ------------------------------------------------------------------ deferred timing
     def new_timer(self):
         t = C.c_void_p()

@@ -14,6 +14,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/pmc_${tag}_$c
   rm -rf $d
   timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
-      python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --calibrate > $d.json 2> $d.err \
+      python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --calibrate > $d.json 2> $d.err \
       || (tail -20 $d.err; exit 1)
 done

@@ -13,5 +13,5 @@ mkdir -p gpurun_out
 d=gpurun_out/pmc_${tag}_VALU
 rm -rf $d
 timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $d -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gather > $d.json 2> $d.err \
+    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-gather > $d.json 2> $d.err \
     || (tail -20 $d.err; exit 1)

@@ -6,6 +6,7 @@ import csv
 import glob
 import json
 import os
+import hashlib
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,7 +37,8 @@ for kern in ("trace", "shade"):
                      issue_frac_vs_simd32_peak=insts * 2.0 / (SIMDS * cyc / XCDS))
 path = os.path.join(HERE, "pmc_valu.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
-allj[workload] = dict(round=tag, kernels=out,
+allj[workload] = dict(
+    kernels_sha16=hashlib.sha256(open(os.path.join(REPO, 'hermespy-rt_amd', 'csrc', 'hrt_kernels.hip'), 'rb').read()).hexdigest()[:16],round=tag, kernels=out,
                       source="rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES (profiles/%s_pmc_valu_%s.csv); "
                              "cycles_per_valu_inst = 1024 SIMDs * busy cycles per XCD / insts; the SIMD-32 peak is "
                              "2 cycles per wave64 instruction, a busy chip sustains 2.3-2.9 on fma/mul/add, 4.2 on "
