@@ -113,12 +113,15 @@ typedef struct {
 static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
 static struct { uint64_t np; float *dirs; uint32_t *order; } g_cache;
 
+static void pool_release_all(void);
+
 void hrt_cache_clear(void)
 {
     pthread_mutex_lock(&g_cache_lock);
     free(g_cache.dirs); free(g_cache.order);
     g_cache.np = 0; g_cache.dirs = NULL; g_cache.order = NULL;
     pthread_mutex_unlock(&g_cache_lock);
+    pool_release_all();
 }
 
 int hrt_launch_cache_enabled(uint64_t np) { return !env_int("HRT_NO_CACHE", 0) && np * 16 <= (1ull << 30); }
@@ -209,11 +212,402 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     c->unblocked[tid] += unb;
 }
 
+/* ---- devices --------------------------------------------------------------------------------
+ * HRT_DEVICES="0,1,2,3" (HIP device ids; an id may repeat: logical devices on one GPU, which is how
+ * the multi-device path is tested on a one-GPU box) or HRT_DEVICE=n (one device, default 0).
+ * compute_paths() is one blocking call (inc/compute_paths.h:59-74); with D devices the round-robin
+ * batches of the launch set (hrt_shard) are dealt to D host threads, one per device, each with its
+ * own problem copy, workspace, streams and page-locked staging; every device copies its records
+ * over its own PCIe link straight into the caller's dense arrays (the slots of different batches are
+ * disjoint: no exchange step, no RCCL). */
+#define HRT_MAX_DEVICES 16
+static int parse_devices(int *dev)
+{
+    const char *v = getenv("HRT_DEVICES");
+    int n = 0;
+    if (v && *v) {
+        const char *q = v;
+        while (*q && n < HRT_MAX_DEVICES) {
+            char *end = NULL;
+            long d = strtol(q, &end, 10);
+            if (end == q) break;
+            dev[n++] = (int)d;
+            q = end;
+            while (*q == ',' || *q == ' ') ++q;
+        }
+    }
+    if (n == 0) { dev[0] = env_int("HRT_DEVICE", 0); n = 1; }
+    return n;
+}
+
+/* ---- buffers kept between calls -------------------------------------------------------------
+ * Device workspace and page-locked staging of the last call, one slot per worker, reused when the
+ * next call fits (same device, capacity >= needed): a warm call saves ~25 ms of hipMalloc /
+ * hipHostMalloc / hipFree on C3.  Released by hrt_cache_clear(); HRT_NO_CACHE=1 disables;
+ * slots holding more than HRT_POOL_MAX_BYTES (default 6 GiB device + pinned) are not kept. */
+typedef struct {
+    int valid, device, with_rays;
+    uint64_t cap, ws_bytes, dirs_rows;
+    work_t w;
+} pool_slot;
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static pool_slot g_pool[HRT_MAX_DEVICES];
+static int g_pool_busy;
+
+static void pool_release_all(void)
+{
+    pthread_mutex_lock(&g_pool_lock);
+    if (!g_pool_busy)
+        for (int k = 0; k < HRT_MAX_DEVICES; ++k)
+            if (g_pool[k].valid) { work_free(&g_pool[k].w); memset(&g_pool[k], 0, sizeof g_pool[k]); }
+    pthread_mutex_unlock(&g_pool_lock);
+}
+
+/* everything one device worker needs */
+typedef struct {
+    /* the call (shared, read-only) */
+    Scene *scene;
+    const Vec3 *rx_pos, *tx_pos, *rx_vel, *tx_vel;
+    float f_ghz;
+    size_t nrx, ntx, np, nb, nq;
+    ChannelInfo *los, *scat;
+    RaysInfo *los_rays, *scat_rays;
+    uint32_t G;                 /* batches = round-robin shards of the launch set */
+    int host_launch, scatter_threads, use_pool;
+    /* this worker */
+    int index, count;           /* handles batches index, index + count, ... */
+    int device;
+    hrt_problem *prob;
+    work_t w;
+    uint64_t cap_alloc, ws_alloc, dirs_rows_alloc;
+    hrt_stats st;
+    double t_dev, t_rb, t_launch;
+    int rc;
+    char err[512];
+} dev_ctx;
+
 #define DL(dst, off, bytes)                                                              \
     do {                                                                                 \
-        rc = hrt_device_download(w.device, (dst), (const uint8_t *)w.d_ws + (off), (bytes)); \
+        rc = hrt_device_download(w->device, (dst), (const uint8_t *)w->d_ws + (off), (bytes)); \
         if (rc) goto done;                                                               \
     } while (0)
+
+/* buffers of one worker, sized for its largest batch (from the pool when they fit) */
+static int worker_alloc(dev_ctx *c)
+{
+    work_t *w = &c->w;
+    const size_t nb = c->nb, nrx = c->nrx, ntx = c->ntx, np = c->np;
+    hrt_layout L;
+    hrt_shard s0 = {np, (uint32_t)c->index, c->G, 0, (uint32_t)nb};
+    int rc = hrt_layout_query(c->prob, &s0, &L);   /* a worker's first batch is never smaller than its others */
+    if (rc) return rc;
+    const uint64_t n_loc_max = hrt_shard_num_local(&(hrt_shard){np, 0, c->G, 0, (uint32_t)nb});
+    const uint64_t cap = L.cap;
+    const int with_rays = c->scat_rays != NULL;
+    if (c->use_pool) {
+        pool_slot *ps = &g_pool[c->index];
+        if (ps->valid && ps->device == c->device && ps->cap >= cap && ps->ws_bytes >= L.total_bytes &&
+            ps->dirs_rows >= n_loc_max + 64 && ps->with_rays >= with_rays) {
+            *w = ps->w;
+            c->cap_alloc = ps->cap; c->ws_alloc = ps->ws_bytes; c->dirs_rows_alloc = ps->dirs_rows;
+            memset(ps, 0, sizeof *ps);
+            w->device = c->device;
+            /* per-call host arrays are not pooled; the small ones sized by nrx / ntx are re-made */
+            w->h_dirs = NULL; w->cur_rays = NULL; w->active = w->next_active = NULL; w->dirs_batch = NULL;
+            free(w->h_los); free(w->run_start); free(w->run_tx);
+            w->h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+            w->run_start = (uint64_t *)malloc((ntx + 2) * sizeof(uint64_t));
+            w->run_tx = (uint32_t *)malloc((ntx + 1) * sizeof(uint32_t));
+            if (!w->h_los || !w->run_start || !w->run_tx) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+            return HRT_OK;
+        }
+        if (ps->valid) { work_free(&ps->w); memset(ps, 0, sizeof *ps); }
+    }
+    memset(w, 0, sizeof *w);
+    w->device = c->device;
+    if ((rc = hrt_device_malloc(w->device, &w->d_ws, L.total_bytes))) return rc;
+    if ((rc = hrt_device_malloc(w->device, &w->d_dirs, (n_loc_max + 64) * 12))) return rc;   /* + rounding of a prefill piece */
+    if ((rc = hrt_device_malloc(w->device, &w->d_order, (n_loc_max + 64) * 4))) return rc;
+    w->h_order = (uint32_t *)malloc((n_loc_max + 64) * 4);
+    w->h_counts = (uint32_t *)calloc(34 + 2, 4);
+    w->h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+    w->run_start = (uint64_t *)malloc((ntx + 2) * sizeof(uint64_t));
+    w->run_tx = (uint32_t *)malloc((ntx + 1) * sizeof(uint32_t));
+    int ok = w->h_order && w->h_counts && w->h_los && w->run_start && w->run_tx;
+    ok &= hrt_hip_host_malloc((void **)&w->ray, cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->tri, cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->mask, cap / 64 * 8 + 8) == 0;
+    for (int k = 0; k < 6 && with_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w->st[k], cap * 4) == 0;
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w->rec[k], cap * 4) == 0;
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w->rec2[k], cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->mask2, cap / 64 * 8 + 8) == 0;
+    ok &= hrt_hip_stream_create(&w->copy_stream) == 0;
+    if (!ok) return hrt_fail(HRT_E_NOMEM, "out of host memory (page-locked staging)");
+    c->cap_alloc = cap; c->ws_alloc = L.total_bytes; c->dirs_rows_alloc = n_loc_max + 64;
+    return HRT_OK;
+}
+
+/* give the buffers back (pool) or free them */
+static void worker_release(dev_ctx *c)
+{
+    work_t *w = &c->w;
+    free(w->h_dirs); w->h_dirs = NULL;
+    free(w->cur_rays); w->cur_rays = NULL;
+    free(w->active); free(w->next_active); w->active = w->next_active = NULL;
+    free(w->dirs_batch); w->dirs_batch = NULL;
+    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (2 + 2 * HRT_REC_FIELDS + 6);
+    if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 6ull << 30)) {
+        if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
+        pool_slot *ps = &g_pool[c->index];
+        ps->valid = 1; ps->device = c->device; ps->with_rays = w->st[0] != NULL;
+        ps->cap = c->cap_alloc; ps->ws_bytes = c->ws_alloc; ps->dirs_rows = c->dirs_rows_alloc;
+        ps->w = *w;
+        memset(w, 0, sizeof *w);
+        return;
+    }
+    work_free(w);
+    memset(w, 0, sizeof *w);
+}
+
+/* one batch (shard g of G) on this worker's device: tables, trace, readback into the dense arrays */
+static int run_batch(dev_ctx *c, uint32_t g)
+{
+    work_t *w = &c->w;
+    hrt_problem *prob = c->prob;
+    const size_t nb = c->nb, nrx = c->nrx, ntx = c->ntx, np = c->np, nq = c->nq;
+    const uint32_t G = c->G, T = prob->num_tri;
+    ChannelInfo *los = c->los, *scat = c->scat;
+    RaysInfo *los_rays = c->los_rays, *scat_rays = c->scat_rays;
+    const Vec3 *rx_pos = c->rx_pos, *tx_pos = c->tx_pos;
+    hrt_stats *st = &c->st;
+    int rc = HRT_OK;
+    hrt_layout L;
+    double t0;
+
+    hrt_shard s = {np, g, G, 0, (uint32_t)nb};
+    const uint64_t n_loc = hrt_shard_num_local(&s);
+    if (n_loc == 0) return HRT_OK;
+    rc = hrt_layout_query(prob, &s, &L);
+    if (rc) goto done;
+    if (c->host_launch) {
+        /* this batch's launch directions: gather from the whole-sphere table */
+        const float *src = w->h_dirs;
+        if (G > 1) {
+            if (!w->dirs_batch) w->dirs_batch = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
+            if (!w->dirs_batch) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            for (uint64_t i = 0; i < n_loc; ++i)
+                memcpy(w->dirs_batch + 3 * i, w->h_dirs + 3 * hrt_shard_global_path(&s, i), 12);
+            src = w->dirs_batch;
+        }
+        t0 = hrt_now_s();
+        if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, NULL, w->h_order))) {
+            if ((rc = hrt_launch_order_host(&s, src, w->h_order))) goto done;
+            if (G == 1) hrt_launch_cache_put(np, w->h_dirs, w->h_order);
+        }
+        c->t_launch += hrt_now_s() - t0;   /* host-side launch preparation */
+        t0 = hrt_now_s();
+        if ((rc = hrt_device_upload(w->device, w->d_dirs, src, n_loc * 12))) goto done;
+        if ((rc = hrt_device_upload(w->device, w->d_order, w->h_order, n_loc * 4))) goto done;
+    } else {
+        t0 = hrt_now_s();
+        if (G > 1 && (rc = hrt_launch_dirs_device(&s, (float *)w->d_dirs, w->device, NULL, NULL))) goto done;
+        if ((rc = hrt_launch_order_device(&s, (uint32_t *)w->d_order, w->device, NULL))) goto done;
+        c->t_launch += hrt_now_s() - t0;
+        t0 = hrt_now_s();
+    }
+    if ((rc = hrt_trace(prob, &s, (const float *)w->d_dirs, (const uint32_t *)w->d_order, w->d_ws, L.total_bytes, NULL, NULL))) goto done;
+    if ((rc = hrt_device_sync(w->device, NULL))) goto done;
+    c->t_dev += hrt_now_s() - t0;
+
+    t0 = hrt_now_s();
+    DL(w->h_counts, L.off_counts, (nb + 2) * 4);
+    if (w->h_counts[nb + 1] != 0) {
+        rc = hrt_fail(HRT_E_HIP, "device reported internal error flags %u", w->h_counts[nb + 1]);
+        goto done;
+    }
+    {
+        hrt_stats bs;
+        hrt_work_from_counts(prob, &s, w->h_counts, &bs);
+        for (size_t b = 0; b <= nb; ++b) st->live[b] += bs.live[b];
+        st->records += bs.records;
+        st->tests += bs.tests - (g ? (uint64_t)nrx * ntx * T : 0);   /* LoS counted once */
+    }
+
+    /* ---- LoS block (identical in every batch; written once, by the owner of batch 0) :515-577 ---- */
+    if (g == 0) {
+        DL(w->h_los, L.off_los, nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
+        for (size_t off = 0; off < nrx * ntx; ++off) los->a_te_im[off] = los->a_tm_im[off] = 0.f;
+        for (size_t rx = 0, off = 0; rx < nrx; ++rx)
+            for (size_t tx = 0; tx < ntx; ++tx, ++off) {
+                const float *q = w->h_los + HRT_LOS_FLOATS * off;
+                uint32_t status;
+                memcpy(&status, &q[HRT_LOS_STATUS], 4);
+                const uint8_t bit = (uint8_t)(1u << (off % 8));
+                if (los_rays) {
+                    Ray *r = &los_rays->rays[off];
+                    r->o = tx_pos[tx];
+                    r->d.x = rx_pos[rx].x - tx_pos[tx].x;
+                    r->d.y = rx_pos[rx].y - tx_pos[tx].y;
+                    r->d.z = rx_pos[rx].z - tx_pos[tx].z;
+                }
+                if (status == 0u) {          /* coincident */
+                    los->directions_rx[off] = (Vec3){1.f, 0.f, 0.f};
+                    los->directions_tx[off] = (Vec3){-1.f, 0.f, 0.f};
+                    los->a_te_re[off] = los->a_tm_re[off] = 1.f;
+                    los->tau[off] = 0.f;
+                    los->freq_shift[off] = 0.f;
+                    if (los_rays) los_rays->rays_active[off / 8] |= bit;
+                } else if (status == 1u) {   /* blocked: Q3 */
+                    los->a_te_re[off] = los->a_tm_re[off] = los->tau[off] = 0.f;
+                    if (los_rays) los_rays->rays_active[off / 8] &= (uint8_t)~bit;
+                } else {
+                    Vec3 u = {q[HRT_LOS_DIRX], q[HRT_LOS_DIRY], q[HRT_LOS_DIRZ]};
+                    los->directions_tx[off] = u;
+                    los->directions_rx[off] = (Vec3){-u.x, -u.y, -u.z};
+                    los->a_te_re[off] = los->a_tm_re[off] = q[HRT_LOS_A];
+                    los->tau[off] = q[HRT_LOS_TAU];
+                    los->freq_shift[off] = q[HRT_LOS_FS];
+                    if (los_rays) los_rays->rays_active[off / 8] |= bit;
+                }
+            }
+    }
+
+    /* ---- bounces: scatter the compact blocks into the dense arrays ---- */
+    for (size_t b = 0; b < nb; ++b) {
+        const uint64_t H = w->h_counts[b + 1];
+        const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
+        if (H) {
+            DL(w->ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
+            DL(w->tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
+            if (scat_rays)
+                for (int k = 0; k < 6; ++k)
+                    DL(w->st[k], hb + (uint64_t)(HRT_HIT_OX + k) * L.cap * 4, H * 4);
+        }
+        /* Q10: the reference adds dot(d - d, mesh_velocity) * f/c -- a signed zero, or NaN for a
+         * non-finite velocity -- to freq_shift[tx*np + path] of every ray that hit (:663-664),
+         * in its loop order (bounce, tx, path), interleaved with the records' "-=" on the same
+         * array.  The two can meet in one slot (the slot tx*np + path is the dense slot of rx 0,
+         * TX (tx*np+path) / (nb*np), ...), and x + (+0) turns a -0 into +0, so the order is
+         * replayed: the hit list is grouped by TX in ascending order (the launch set is, and the
+         * compaction is stable), and per TX the adds go first, then that TX's records. */
+        /* records of (b, rx): D2H into one of two page-locked staging sets on a copy stream,
+         * so that the copy of block rx+1 runs while the host threads scatter block rx */
+#define FETCH_RX(RX, SET_REC, SET_MASK, I0, I1)                                                      \
+    do {                                                                                             \
+        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
+        const uint64_t i0_ = (I0), n_ = (I1) - (I0), w0_ = (I0) / 64, w1_ = ((I1) + 63) / 64;         \
+        int e_ = 0;                                                                                  \
+        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
+            e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w->d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, w->copy_stream); \
+        if (!e_)                                                                                     \
+            e_ = hrt_hip_d2h_async((SET_MASK) + w0_, (const uint8_t *)w->d_ws + L.off_masks + (((uint64_t)b * nrx + (RX)) * (L.cap / 64) + w0_) * 8, \
+                                   (w1_ - w0_) * 8, w->copy_stream);                                 \
+        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
+    } while (0)
+        /* runs of equal TX in the hit list (at most ntx) */
+        uint64_t nruns = 0;
+        if (H) {
+            uint32_t cur = (uint32_t)(w->ray[0] / n_loc);
+            w->run_start[0] = 0; w->run_tx[0] = cur; nruns = 1;
+            for (;;) {   /* run boundaries by bisection on the (ascending) TX of the entries */
+                uint64_t lo_i = w->run_start[nruns - 1], hi_i = H;
+                const uint32_t t_cur = w->run_tx[nruns - 1];
+                while (lo_i < hi_i) {   /* first entry with tx > t_cur */
+                    const uint64_t mid = (lo_i + hi_i) / 2;
+                    if ((uint32_t)(w->ray[mid] / n_loc) > t_cur) hi_i = mid; else lo_i = mid + 1;
+                }
+                if (lo_i >= H) break;
+                if (nruns >= ntx) { rc = hrt_fail(HRT_E_HIP, "hit list is not grouped by TX"); goto done; }
+                w->run_start[nruns] = lo_i;
+                w->run_tx[nruns] = (uint32_t)(w->ray[lo_i] / n_loc);
+                ++nruns;
+            }
+            w->run_start[nruns] = H;
+        }
+        /* with one run (one TX, the common case) the copy of block rx+1 overlaps the scatter of
+         * block rx; with several runs the blocks are fetched run by run (the reference's order is
+         * (tx, path, rx)) */
+        for (uint64_t run = 0; run < nruns; ++run) {
+            const uint64_t r0 = w->run_start[run], r1 = w->run_start[run + 1];
+            const size_t txr = w->run_tx[run];
+            for (uint64_t i = r0; i < r1; ++i) {
+                const uint64_t p = hrt_shard_global_path(&s, w->ray[i] - txr * n_loc);
+                const float *mv = prob->h_mesh + (size_t)prob->h_tri_mesh[w->tri[i]] * HRT_MESH_FLOATS;
+                const float zero = 0.f;   /* d - d with finite d */
+                float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
+                scat->freq_shift[txr * np + p] += z * prob->dop_mult;
+            }
+            if (run == 0) FETCH_RX(0, w->rec, w->mask, r0, r1);
+            for (size_t rx = 0; rx < nrx; ++rx) {
+                const size_t slot = (size_t)(run * nrx + rx);
+                float *const *cur_rec = (slot & 1) ? w->rec2 : w->rec;
+                const uint64_t *cur_mask = (slot & 1) ? w->mask2 : w->mask;
+                {
+                    const int e = hrt_hip_stream_sync(w->copy_stream);   /* block rx has landed */
+                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
+                }
+                if (rx + 1 < nrx || run + 1 < nruns) {   /* next block: rx+1, or rx 0 of the next run */
+                    const size_t nrx_next = (rx + 1 < nrx) ? rx + 1 : 0;
+                    const uint64_t n0_ = (rx + 1 < nrx) ? r0 : w->run_start[run + 1];
+                    const uint64_t n1_ = (rx + 1 < nrx) ? r1 : w->run_start[run + 2];
+                    if (slot & 1) FETCH_RX(nrx_next, w->rec, w->mask, n0_, n1_);
+                    else FETCH_RX(nrx_next, w->rec2, w->mask2, n0_, n1_);
+                }
+                {
+                    scatter_ctx sc;
+                    memset(&sc, 0, sizeof sc);
+                    sc.s = &s; sc.ray = w->ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
+                    sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
+                    sc.i_base = r0;
+                    hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
+                    for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st->records_unblocked += sc.unblocked[t];
+                }
+            }
+        }
+#undef FETCH_RX
+
+        /* ---- RaysInfo snapshots (:732-743) ---- */
+        if (scat_rays && G == 1) {
+            memset(w->next_active, 0, nq / 8);           /* bits >= nq keep their ones */
+            w->next_active[nq / 8] = w->active[nq / 8];
+            for (size_t q = nq - nq % 8; q < nq; ++q) w->next_active[q / 8] &= (uint8_t)~(1u << (q % 8));
+            for (uint64_t i = 0; i < H; ++i) {
+                const uint32_t q = w->ray[i];            /* one batch: local id == tx*np+p */
+                w->next_active[q / 8] |= (uint8_t)(1u << (q % 8));
+                Ray *r = &w->cur_rays[q];
+                r->o = (Vec3){w->st[0][i], w->st[1][i], w->st[2][i]};
+                r->d = (Vec3){w->st[3][i], w->st[4][i], w->st[5][i]};
+            }
+            const size_t nbytes = np / 8 + 1;
+            for (size_t tx = 0; tx < ntx; ++tx) {
+                const size_t off_rays = (tx * nb + (b + 1)) * np;
+                const size_t off_act = (tx * nb + (b + 1)) * nbytes;
+                memcpy(scat_rays->rays + off_rays, w->cur_rays + tx * np, np * sizeof(Ray));
+                uint8_t *dst = scat_rays->rays_active + off_act;
+                memcpy(dst, w->next_active, nbytes);
+                if (tx == 0 && ntx > 1)   /* Q12: tx1's first bits are still last bounce's */
+                    for (size_t bitp = np; bitp < 8 * nbytes; ++bitp) {
+                        uint8_t m = (uint8_t)(1u << (bitp % 8));
+                        dst[bitp / 8] = (uint8_t)((dst[bitp / 8] & ~m) | (w->active[bitp / 8] & m));
+                    }
+            }
+            uint8_t *sw = w->active; w->active = w->next_active; w->next_active = sw;
+        }
+    }
+    c->t_rb += hrt_now_s() - t0;
+done:
+    return rc;
+}
+
+static void *worker_main(void *arg)
+{
+    dev_ctx *c = (dev_ctx *)arg;
+    int rc = HRT_OK;
+    for (uint32_t g = (uint32_t)c->index; g < c->G && !rc; g += (uint32_t)c->count) rc = run_batch(c, g);
+    c->rc = rc;
+    if (rc) snprintf(c->err, sizeof c->err, "%s", hrt_last_error());
+    return NULL;
+}
 
 int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                          const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t nrx,
@@ -227,17 +621,33 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
 
     hrt_stats st;
     memset(&st, 0, sizeof st);
-    work_t w;
-    memset(&w, 0, sizeof w);
-    w.device = env_int("HRT_DEVICE", 0);
-    st.device = w.device;
-    hrt_problem *prob = NULL;
-    int rc = hrt_problem_create(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, w.device,
-                                &prob);
-    if (rc) return rc;
-    const uint32_t T = prob->num_tri;
+    int devs[HRT_MAX_DEVICES];
+    int D = parse_devices(devs);
+    /* RaysInfo snapshots copy the state of EVERY ray after each bounce: one batch, one device */
+    if (scat_rays) D = 1;
+    dev_ctx *ctx = (dev_ctx *)calloc((size_t)D, sizeof(dev_ctx));
+    if (!ctx) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    st.device = devs[0];
     const size_t nq = ntx * np;
-    const int scatter_threads = hrt_host_threads();
+    int rc = HRT_OK;
+    int pool_taken = 0;
+    double t0;
+
+    for (int d = 0; d < D; ++d) {
+        dev_ctx *c = &ctx[d];
+        c->scene = scene; c->rx_pos = rx_pos; c->tx_pos = tx_pos; c->rx_vel = rx_vel; c->tx_vel = tx_vel;
+        c->f_ghz = f_ghz; c->nrx = nrx; c->ntx = ntx; c->np = np; c->nb = nb; c->nq = nq;
+        c->los = los; c->scat = scat; c->los_rays = los_rays; c->scat_rays = scat_rays;
+        c->index = d; c->count = D; c->device = devs[d];
+        c->host_launch = env_int("HRT_HOST_LAUNCH", 0);
+        int thr = hrt_host_threads() / D;
+        c->scatter_threads = thr > 0 ? thr : 1;
+    }
+    /* one problem per device (the scene is tiny; every device holds all of it) */
+    for (int d = 0; d < D && !rc; ++d)
+        rc = hrt_problem_create(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, ctx[d].device, &ctx[d].prob);
+    if (rc) goto done;
+    hrt_problem *prob = ctx[0].prob;
 
     /* normals: the reference leaves them in the scene for the caller (:208-224) */
     {
@@ -255,366 +665,179 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     }
     st.t_setup_s = hrt_now_s() - t_begin;
 
-    /* ---- launch tables.  Default: generated ON THE DEVICE (directions bit-identical to the host
-     * libm's, hrt_launch_dirs_device; coherent order by hrt_launch_order_device), after the buffers
-     * exist (below).  HRT_HOST_LAUNCH=1: the host generators + the launch-table cache. ---- */
-    const int host_launch = env_int("HRT_HOST_LAUNCH", 0);
-    double t0 = hrt_now_s();
-    hrt_shard whole = {np, 0, 1, 0, (uint32_t)nb};
-    if (host_launch) {
-        w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
-        if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-        if (!(hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, w.h_dirs, NULL))) {
-            rc = hrt_launch_dirs_host(&whole, w.h_dirs, env_int("HRT_HOST_THREADS", 0));
-            if (rc) goto done;
-            hrt_launch_cache_put(np, w.h_dirs, NULL);
+    /* ---- batches: how many round-robin shards so one workspace fits the budget, at least one per
+     * device, a multiple of the device count ---- */
+    uint32_t G = 1;
+    {
+        uint64_t free_b = 0, total_b = 0;
+        rc = hrt_device_mem_info(ctx[0].device, &free_b, &total_b);
+        if (rc) goto done;
+        uint64_t budget = env_u64("HRT_WORKSPACE_BYTES", 0);
+        if (!budget) {
+            budget = free_b / 2;
+            if (budget > (16ull << 30)) budget = 16ull << 30;
+            /* logical devices on one GPU share its memory */
+            int same = 0;
+            for (int d = 0; d < D; ++d) same += ctx[d].device == ctx[0].device;
+            budget /= (uint64_t)(same > 0 ? same : 1);
+        }
+        hrt_layout L;
+        for (; !scat_rays;) {
+            hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
+            rc = hrt_layout_query(prob, &s, &L);
+            if (rc == HRT_OK && G >= (uint32_t)D && L.total_bytes + hrt_shard_num_local(&s) * 12 <= budget) break;
+            if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
+            if ((uint64_t)G * 4096 >= np) {   /* one granule per batch and still too big */
+                if (rc == HRT_OK) break;      /* try anyway; hipMalloc decides */
+                goto done;
+            }
+            G *= 2;
+        }
+        rc = HRT_OK;
+        if (G > 1 && G % (uint32_t)D) G = (G / (uint32_t)D + 1) * (uint32_t)D;
+        if ((uint64_t)G * 4096 > np + 4095) {   /* fewer granules than batches: fewer workers */
+            G = (uint32_t)((np + 4095) / 4096);
+            if (G < 1) G = 1;
+        }
+        if ((uint32_t)D > G) D = (int)G;
+    }
+    for (int d = 0; d < D; ++d) { ctx[d].G = G; ctx[d].count = D; }
+
+    /* ---- buffers (pooled between calls) ---- */
+    if (!env_int("HRT_NO_CACHE", 0)) {
+        pthread_mutex_lock(&g_pool_lock);
+        if (!g_pool_busy) { g_pool_busy = 1; pool_taken = 1; }
+        pthread_mutex_unlock(&g_pool_lock);
+    }
+    for (int d = 0; d < D && !rc; ++d) {
+        ctx[d].use_pool = pool_taken;
+        rc = worker_alloc(&ctx[d]);
+    }
+    if (rc) goto done;
+
+    /* ---- launch tables + the dense pre-fills that do not depend on the trace.  Default: tables
+     * generated ON THE DEVICE (directions bit-identical to the host libm's, hrt_launch_dirs_device;
+     * coherent order by hrt_launch_order_device).  HRT_HOST_LAUNCH=1: the host generators + the
+     * launch-table cache. ---- */
+    {
+        work_t *w = &ctx[0].w;
+        const int host_launch = ctx[0].host_launch;
+        t0 = hrt_now_s();
+        hrt_shard whole = {np, 0, 1, 0, (uint32_t)nb};
+        if (host_launch) {
+            w->h_dirs = (float *)malloc(np * 3 * sizeof(float));
+            if (!w->h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            if (!(hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, w->h_dirs, NULL))) {
+                rc = hrt_launch_dirs_host(&whole, w->h_dirs, env_int("HRT_HOST_THREADS", 0));
+                if (rc) goto done;
+                hrt_launch_cache_put(np, w->h_dirs, NULL);
+            }
+            /* Q9, literally: launch term at [tx*np*nb + p] (the memcpy replications follow below) */
+            for (size_t tx = 0; tx < ntx; ++tx)
+                for (size_t p = 0; p < np; ++p) {
+                    const float *d = w->h_dirs + 3 * p;
+                    float v = tx_vel[tx].x * d[0] + tx_vel[tx].y * d[1] + tx_vel[tx].z * d[2];
+                    scat->freq_shift[tx * np * nb + p] = v * prob->dop_mult;
+                }
+            for (int d = 1; d < D; ++d) ctx[d].w.h_dirs = w->h_dirs;   /* shared, read-only; freed by worker 0 */
+        } else {
+            /* the launch Doppler term of every path (Q9) from directions generated on the device, in
+             * pieces that fit the direction buffer: a "shard" with one granule per rank is a contiguous
+             * range of the sphere.  With one batch the single piece is the whole launch set and its
+             * directions stay in d_dirs for the trace. */
+            const uint64_t n_buf = hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb});
+            uint32_t pieces = (uint32_t)((np + n_buf - 1) / n_buf);
+            uint64_t piece = ((np + pieces - 1) / pieces + 63) / 64 * 64;
+            if (G == 1) { pieces = 1; piece = 0; }
+            for (uint32_t k = 0; k < pieces; ++k) {
+                hrt_shard ps = {np, k, pieces, (uint32_t)piece, (uint32_t)nb};
+                const uint64_t n_p = hrt_shard_num_local(&ps);
+                if (n_p == 0) continue;
+                const uint64_t a = hrt_shard_global_path(&ps, 0);
+                if ((rc = hrt_launch_dirs_device(&ps, (float *)w->d_dirs, w->device, NULL, NULL))) goto done;
+                for (size_t tx = 0; tx < ntx; ++tx) {
+                    const float tv[3] = {tx_vel[tx].x, tx_vel[tx].y, tx_vel[tx].z};
+                    int e = hrt_hip_launch_fs0((const float *)w->d_dirs, n_p, tv, prob->dop_mult, (float *)w->d_ws, NULL);
+                    if (e) { rc = hrt_fail_hip(e, "hrt_fs0_kernel"); goto done; }
+                    if ((rc = hrt_device_download(w->device, scat->freq_shift + tx * np * nb + a, w->d_ws, n_p * 4))) goto done;
+                }
+            }
+            if (scat_rays) {   /* RaysInfo needs the directions on the host (one batch: they are in d_dirs) */
+                w->h_dirs = (float *)malloc(np * 3 * sizeof(float));
+                if (!w->h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+                if ((rc = hrt_device_download(w->device, w->h_dirs, w->d_dirs, np * 12))) goto done;
+            }
         }
         st.t_launch_dirs_s = hrt_now_s() - t0;
-        /* Q9, literally: launch term at [tx*np*nb + p] (the memcpy replications follow below) */
-        for (size_t tx = 0; tx < ntx; ++tx)
-            for (size_t p = 0; p < np; ++p) {
-                const float *d = w.h_dirs + 3 * p;
-                float v = tx_vel[tx].x * d[0] + tx_vel[tx].y * d[1] + tx_vel[tx].z * d[2];
-                scat->freq_shift[tx * np * nb + p] = v * prob->dop_mult;
+        /* Q9: the two memcpy replications of the launch term */
+        for (size_t b = 1; b < nb; ++b)
+            memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
+        for (size_t rx = 1; rx < nrx; ++rx)
+            memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
+
+        if (scat_rays) {
+            /* :469-471 and :589 */
+            for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
+            w->cur_rays = (Ray *)malloc(nq * sizeof(Ray));
+            w->active = (uint8_t *)malloc(nq / 8 + 1);
+            w->next_active = (uint8_t *)malloc(nq / 8 + 1);
+            if (!w->cur_rays || !w->active || !w->next_active) {
+                rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
+                goto done;
             }
+            memset(w->active, 0xff, nq / 8 + 1);
+            for (size_t tx = 0; tx < ntx; ++tx)
+                for (size_t p = 0; p < np; ++p) {
+                    Ray *r = &w->cur_rays[tx * np + p];
+                    r->o = tx_pos[tx];
+                    memcpy(&r->d, w->h_dirs + 3 * p, sizeof(Vec3));
+                }
+            memcpy(scat_rays->rays, w->cur_rays, nq * sizeof(Ray));
+        }
     }
 
-    /* ---- batches: how many round-robin shards so one workspace fits the budget ---- */
-    uint64_t free_b = 0, total_b = 0;
-    rc = hrt_device_mem_info(w.device, &free_b, &total_b);
-    if (rc) goto done;
-    uint64_t budget = env_u64("HRT_WORKSPACE_BYTES", 0);
-    if (!budget) {
-        budget = free_b / 2;
-        if (budget > (16ull << 30)) budget = 16ull << 30;
-    }
-    uint32_t G = 1;
-    hrt_layout L;
-    /* RaysInfo snapshots copy the state of EVERY ray after each bounce, so that output needs
-     * the whole launch set in one batch; without it the batches are independent. */
-    for (; !scat_rays;) {
-        hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
-        rc = hrt_layout_query(prob, &s, &L);
-        if (rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 12 <= budget) break;
-        if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
-        if ((uint64_t)G * 4096 >= np) {   /* one granule per batch and still too big */
-            if (rc == HRT_OK) break;      /* try anyway; hipMalloc decides */
-            goto done;
-        }
-        G *= 2;
-    }
+    /* ---- the batches: one host thread per device ---- */
     {
-        hrt_shard s0 = {np, 0, G, 0, (uint32_t)nb};
-        rc = hrt_layout_query(prob, &s0, &L);   /* rank 0 is never smaller than the others */
-        if (rc) goto done;
-        const uint64_t n_loc_max = hrt_shard_num_local(&s0);
-        const uint64_t cap = L.cap;
-        if ((rc = hrt_device_malloc(w.device, &w.d_ws, L.total_bytes))) goto done;
-        if ((rc = hrt_device_malloc(w.device, &w.d_dirs, (n_loc_max + 64) * 12))) goto done;   /* + rounding of a prefill piece */
-        if ((rc = hrt_device_malloc(w.device, &w.d_order, n_loc_max * 4))) goto done;
-        w.h_order = (uint32_t *)malloc(n_loc_max * 4);
-        if (!w.h_order) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-        w.h_counts = (uint32_t *)calloc(nb + 2, 4);
-        w.h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
-        int ok = w.h_counts && w.h_los;
-        ok &= hrt_hip_host_malloc((void **)&w.ray, cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&w.tri, cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&w.mask, cap / 64 * 8 + 8) == 0;
-        for (int k = 0; k < 6 && scat_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w.st[k], cap * 4) == 0;
-        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w.rec[k], cap * 4) == 0;
-        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w.rec2[k], cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&w.mask2, cap / 64 * 8 + 8) == 0;
-        ok &= hrt_hip_stream_create(&w.copy_stream) == 0;
-        if (!ok) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+        pthread_t th[HRT_MAX_DEVICES];
+        int started[HRT_MAX_DEVICES] = {0};
+        for (int d = 1; d < D; ++d) started[d] = pthread_create(&th[d], NULL, worker_main, &ctx[d]) == 0;
+        worker_main(&ctx[0]);
+        for (int d = 1; d < D; ++d) {
+            if (started[d]) pthread_join(th[d], NULL);
+            else worker_main(&ctx[d]);   /* a thread that would not start: run its batches here */
+        }
+        for (int d = 0; d < D; ++d) {
+            if (ctx[d].rc && !rc) rc = hrt_fail(ctx[d].rc, "device %d: %s", ctx[d].device, ctx[d].err);
+            for (size_t b = 0; b <= nb; ++b) st.live[b] += ctx[d].st.live[b];
+            st.records += ctx[d].st.records;
+            st.records_unblocked += ctx[d].st.records_unblocked;
+            st.tests += ctx[d].st.tests;
+            /* phases: the slowest device */
+            if (ctx[d].t_dev > st.t_device_s) st.t_device_s = ctx[d].t_dev;
+            if (ctx[d].t_rb > st.t_readback_s) st.t_readback_s = ctx[d].t_rb;
+            st.t_launch_dirs_s += ctx[d].t_launch / D;
+        }
     }
-
-    double t_dev = 0.0, t_rb = 0.0;
-
-    if (!host_launch) {
-        /* the launch Doppler term of every path (Q9) from directions generated on the device, in
-         * pieces that fit the direction buffer: a "shard" with one granule per rank is a contiguous
-         * range of the sphere.  With one batch the single piece is the whole launch set and its
-         * directions stay in w.d_dirs for the trace. */
-        t0 = hrt_now_s();
-        const uint64_t n_buf = hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb});
-        uint32_t pieces = (uint32_t)((np + n_buf - 1) / n_buf);
-        uint64_t piece = ((np + pieces - 1) / pieces + 63) / 64 * 64;
-        if (G == 1) { pieces = 1; piece = 0; }
-        for (uint32_t k = 0; k < pieces; ++k) {
-            hrt_shard ps = {np, k, pieces, (uint32_t)piece, (uint32_t)nb};
-            const uint64_t n_p = hrt_shard_num_local(&ps);
-            if (n_p == 0) continue;
-            const uint64_t a = hrt_shard_global_path(&ps, 0);
-            if ((rc = hrt_launch_dirs_device(&ps, (float *)w.d_dirs, w.device, NULL, NULL))) goto done;
-            for (size_t tx = 0; tx < ntx; ++tx) {
-                const float tv[3] = {tx_vel[tx].x, tx_vel[tx].y, tx_vel[tx].z};
-                int e = hrt_hip_launch_fs0((const float *)w.d_dirs, n_p, tv, prob->dop_mult, (float *)w.d_ws, NULL);
-                if (e) { rc = hrt_fail_hip(e, "hrt_fs0_kernel"); goto done; }
-                if ((rc = hrt_device_download(w.device, scat->freq_shift + tx * np * nb + a, w.d_ws, n_p * 4))) goto done;
-            }
-        }
-        if (scat_rays) {   /* RaysInfo needs the directions on the host (one batch: they are in w.d_dirs) */
-            w.h_dirs = (float *)malloc(np * 3 * sizeof(float));
-            if (!w.h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-            if ((rc = hrt_device_download(w.device, w.h_dirs, w.d_dirs, np * 12))) goto done;
-        }
-        st.t_launch_dirs_s += hrt_now_s() - t0;
-    }
-    /* Q9: the two memcpy replications of the launch term */
-    for (size_t b = 1; b < nb; ++b)
-        memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
-    for (size_t rx = 1; rx < nrx; ++rx)
-        memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
-
-    if (scat_rays) {
-        /* :469-471 and :589 */
-        for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
-        w.cur_rays = (Ray *)malloc(nq * sizeof(Ray));
-        w.active = (uint8_t *)malloc(nq / 8 + 1);
-        w.next_active = (uint8_t *)malloc(nq / 8 + 1);
-        if (!w.cur_rays || !w.active || !w.next_active) {
-            rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
-            goto done;
-        }
-        memset(w.active, 0xff, nq / 8 + 1);
-        for (size_t tx = 0; tx < ntx; ++tx)
-            for (size_t p = 0; p < np; ++p) {
-                Ray *r = &w.cur_rays[tx * np + p];
-                r->o = tx_pos[tx];
-                memcpy(&r->d, w.h_dirs + 3 * p, sizeof(Vec3));
-            }
-        memcpy(scat_rays->rays, w.cur_rays, nq * sizeof(Ray));
-    }
-
-    for (uint32_t g = 0; g < G; ++g) {
-        hrt_shard s = {np, g, G, 0, (uint32_t)nb};
-        const uint64_t n_loc = hrt_shard_num_local(&s);
-        if (n_loc == 0) continue;
-        rc = hrt_layout_query(prob, &s, &L);
-        if (rc) goto done;
-        if (host_launch) {
-            /* this batch's launch directions: gather from the whole-sphere table */
-            const float *src = w.h_dirs;
-            if (G > 1) {
-                if (!w.dirs_batch) w.dirs_batch = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
-                if (!w.dirs_batch) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-                for (uint64_t i = 0; i < n_loc; ++i)
-                    memcpy(w.dirs_batch + 3 * i, w.h_dirs + 3 * hrt_shard_global_path(&s, i), 12);
-                src = w.dirs_batch;
-            }
-            t0 = hrt_now_s();
-            if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, NULL, w.h_order))) {
-                if ((rc = hrt_launch_order_host(&s, src, w.h_order))) goto done;
-                if (G == 1) hrt_launch_cache_put(np, w.h_dirs, w.h_order);
-            }
-            st.t_launch_dirs_s += hrt_now_s() - t0;   /* host-side launch preparation */
-            t0 = hrt_now_s();
-            if ((rc = hrt_device_upload(w.device, w.d_dirs, src, n_loc * 12))) goto done;
-            if ((rc = hrt_device_upload(w.device, w.d_order, w.h_order, n_loc * 4))) goto done;
-        } else {
-            t0 = hrt_now_s();
-            if (G > 1 && (rc = hrt_launch_dirs_device(&s, (float *)w.d_dirs, w.device, NULL, NULL))) goto done;
-            if ((rc = hrt_launch_order_device(&s, (uint32_t *)w.d_order, w.device, NULL))) goto done;
-            st.t_launch_dirs_s += hrt_now_s() - t0;
-            t0 = hrt_now_s();
-        }
-        if ((rc = hrt_trace(prob, &s, (const float *)w.d_dirs, (const uint32_t *)w.d_order, w.d_ws, L.total_bytes, NULL, NULL))) goto done;
-        if ((rc = hrt_device_sync(w.device, NULL))) goto done;
-        t_dev += hrt_now_s() - t0;
-
-        t0 = hrt_now_s();
-        DL(w.h_counts, L.off_counts, (nb + 2) * 4);
-        if (w.h_counts[nb + 1] != 0) {
-            rc = hrt_fail(HRT_E_HIP, "device reported internal error flags %u", w.h_counts[nb + 1]);
-            goto done;
-        }
-        {
-            hrt_stats bs;
-            hrt_work_from_counts(prob, &s, w.h_counts, &bs);
-            for (size_t b = 0; b <= nb; ++b) st.live[b] += bs.live[b];
-            st.records += bs.records;
-            st.tests += bs.tests - (g ? (uint64_t)nrx * ntx * T : 0);   /* LoS counted once */
-        }
-
-        /* ---- LoS block (identical in every batch; written once) :515-577 ---- */
-        if (g == 0) {
-            DL(w.h_los, L.off_los, nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
-            for (size_t off = 0; off < nrx * ntx; ++off) los->a_te_im[off] = los->a_tm_im[off] = 0.f;
-            for (size_t rx = 0, off = 0; rx < nrx; ++rx)
-                for (size_t tx = 0; tx < ntx; ++tx, ++off) {
-                    const float *q = w.h_los + HRT_LOS_FLOATS * off;
-                    uint32_t status;
-                    memcpy(&status, &q[HRT_LOS_STATUS], 4);
-                    const uint8_t bit = (uint8_t)(1u << (off % 8));
-                    if (los_rays) {
-                        Ray *r = &los_rays->rays[off];
-                        r->o = tx_pos[tx];
-                        r->d.x = rx_pos[rx].x - tx_pos[tx].x;
-                        r->d.y = rx_pos[rx].y - tx_pos[tx].y;
-                        r->d.z = rx_pos[rx].z - tx_pos[tx].z;
-                    }
-                    if (status == 0u) {          /* coincident */
-                        los->directions_rx[off] = (Vec3){1.f, 0.f, 0.f};
-                        los->directions_tx[off] = (Vec3){-1.f, 0.f, 0.f};
-                        los->a_te_re[off] = los->a_tm_re[off] = 1.f;
-                        los->tau[off] = 0.f;
-                        los->freq_shift[off] = 0.f;
-                        if (los_rays) los_rays->rays_active[off / 8] |= bit;
-                    } else if (status == 1u) {   /* blocked: Q3 */
-                        los->a_te_re[off] = los->a_tm_re[off] = los->tau[off] = 0.f;
-                        if (los_rays) los_rays->rays_active[off / 8] &= (uint8_t)~bit;
-                    } else {
-                        Vec3 u = {q[HRT_LOS_DIRX], q[HRT_LOS_DIRY], q[HRT_LOS_DIRZ]};
-                        los->directions_tx[off] = u;
-                        los->directions_rx[off] = (Vec3){-u.x, -u.y, -u.z};
-                        los->a_te_re[off] = los->a_tm_re[off] = q[HRT_LOS_A];
-                        los->tau[off] = q[HRT_LOS_TAU];
-                        los->freq_shift[off] = q[HRT_LOS_FS];
-                        if (los_rays) los_rays->rays_active[off / 8] |= bit;
-                    }
-                }
-        }
-
-        /* ---- bounces: scatter the compact blocks into the dense arrays ---- */
-        for (size_t b = 0; b < nb; ++b) {
-            const uint64_t H = w.h_counts[b + 1];
-            const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
-            if (H) {
-                DL(w.ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
-                DL(w.tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
-                if (scat_rays)
-                    for (int k = 0; k < 6; ++k)
-                        DL(w.st[k], hb + (uint64_t)(HRT_HIT_OX + k) * L.cap * 4, H * 4);
-            }
-            /* Q10: the reference adds dot(d - d, mesh_velocity) * f/c -- a signed zero, or NaN for a
-             * non-finite velocity -- to freq_shift[tx*np + path] of every ray that hit (:663-664),
-             * in its loop order (bounce, tx, path), interleaved with the records' "-=" on the same
-             * array.  The two can meet in one slot (the slot tx*np + path is the dense slot of rx 0,
-             * TX (tx*np+path) / (nb*np), ...), and x + (+0) turns a -0 into +0, so the order is
-             * replayed: the hit list is grouped by TX in ascending order (the launch set is, and the
-             * compaction is stable), and per TX the adds go first, then that TX's records. */
-            /* records of (b, rx): D2H into one of two page-locked staging sets on a copy stream,
-             * so that the copy of block rx+1 runs while the host threads scatter block rx */
-#define FETCH_RX(RX, SET_REC, SET_MASK, I0, I1)                                                      \
-    do {                                                                                             \
-        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
-        const uint64_t i0_ = (I0), n_ = (I1) - (I0), w0_ = (I0) / 64, w1_ = ((I1) + 63) / 64;         \
-        int e_ = 0;                                                                                  \
-        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
-            e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w.d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, w.copy_stream); \
-        if (!e_)                                                                                     \
-            e_ = hrt_hip_d2h_async((SET_MASK) + w0_, (const uint8_t *)w.d_ws + L.off_masks + (((uint64_t)b * nrx + (RX)) * (L.cap / 64) + w0_) * 8, \
-                                   (w1_ - w0_) * 8, w.copy_stream);                                  \
-        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
-    } while (0)
-            /* runs of equal TX in the hit list (at most ntx) */
-            uint64_t nruns = 0;
-            if (H) {
-                if (!w.run_start) {
-                    w.run_start = (uint64_t *)malloc((ntx + 1) * sizeof(uint64_t));
-                    w.run_tx = (uint32_t *)malloc(ntx * sizeof(uint32_t));
-                    if (!w.run_start || !w.run_tx) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-                }
-                uint32_t cur = (uint32_t)(w.ray[0] / n_loc);
-                w.run_start[0] = 0; w.run_tx[0] = cur; nruns = 1;
-                /* run boundaries by bisection on the (ascending) TX of the entries */
-                while (w.run_tx[nruns - 1] + 1u < ntx || 1) {
-                    uint64_t lo_i = w.run_start[nruns - 1], hi_i = H;
-                    const uint32_t t_cur = w.run_tx[nruns - 1];
-                    while (lo_i < hi_i) {   /* first entry with tx > t_cur */
-                        const uint64_t mid = (lo_i + hi_i) / 2;
-                        if ((uint32_t)(w.ray[mid] / n_loc) > t_cur) hi_i = mid; else lo_i = mid + 1;
-                    }
-                    if (lo_i >= H) break;
-                    if (nruns >= ntx) { rc = hrt_fail(HRT_E_HIP, "hit list is not grouped by TX"); goto done; }
-                    w.run_start[nruns] = lo_i;
-                    w.run_tx[nruns] = (uint32_t)(w.ray[lo_i] / n_loc);
-                    ++nruns;
-                }
-                w.run_start[nruns] = H;
-            }
-            /* all rx blocks of this bounce are needed per TX run: with one run (one TX, the common
-             * case) the copy of block rx+1 overlaps the scatter of block rx; with several runs the
-             * blocks are fetched once per run (the reference's order is (tx, path, rx)) */
-            for (uint64_t run = 0; run < nruns; ++run) {
-                const uint64_t r0 = w.run_start[run], r1 = w.run_start[run + 1];
-                const size_t txr = w.run_tx[run];
-                for (uint64_t i = r0; i < r1; ++i) {
-                    const uint64_t p = hrt_shard_global_path(&s, w.ray[i] - txr * n_loc);
-                    const float *mv = prob->h_mesh + (size_t)prob->h_tri_mesh[w.tri[i]] * HRT_MESH_FLOATS;
-                    const float zero = 0.f;   /* d - d with finite d */
-                    float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
-                    scat->freq_shift[txr * np + p] += z * prob->dop_mult;
-                }
-                if (run == 0) FETCH_RX(0, w.rec, w.mask, r0, r1);
-                for (size_t rx = 0; rx < nrx; ++rx) {
-                    const size_t slot = (size_t)(run * nrx + rx);
-                    float *const *cur_rec = (slot & 1) ? w.rec2 : w.rec;
-                    const uint64_t *cur_mask = (slot & 1) ? w.mask2 : w.mask;
-                    {
-                        const int e = hrt_hip_stream_sync(w.copy_stream);   /* block rx has landed */
-                        if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
-                    }
-                    if (rx + 1 < nrx || run + 1 < nruns) {   /* next block: rx+1, or rx 0 of the next run */
-                        const size_t nrx_next = (rx + 1 < nrx) ? rx + 1 : 0;
-                        const uint64_t n0_ = (rx + 1 < nrx) ? r0 : w.run_start[run + 1];
-                        const uint64_t n1_ = (rx + 1 < nrx) ? r1 : w.run_start[run + 2];
-                        if (slot & 1) FETCH_RX(nrx_next, w.rec, w.mask, n0_, n1_);
-                        else FETCH_RX(nrx_next, w.rec2, w.mask2, n0_, n1_);
-                    }
-                    {
-                        scatter_ctx sc;
-                        memset(&sc, 0, sizeof sc);
-                        sc.s = &s; sc.ray = w.ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
-                        sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
-                        sc.i_base = r0;
-                        hrt_parallel_ranges(scatter_range, &sc, r1 - r0, scatter_threads);
-                        for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st.records_unblocked += sc.unblocked[t];
-                    }
-                }
-            }
-#undef FETCH_RX
-
-            /* ---- RaysInfo snapshots (:732-743) ---- */
-            if (scat_rays && G == 1) {
-                memset(w.next_active, 0, nq / 8);           /* bits >= nq keep their ones */
-                w.next_active[nq / 8] = w.active[nq / 8];
-                for (size_t q = nq - nq % 8; q < nq; ++q) w.next_active[q / 8] &= (uint8_t)~(1u << (q % 8));
-                for (uint64_t i = 0; i < H; ++i) {
-                    const uint32_t q = w.ray[i];            /* one batch: local id == tx*np+p */
-                    w.next_active[q / 8] |= (uint8_t)(1u << (q % 8));
-                    Ray *r = &w.cur_rays[q];
-                    r->o = (Vec3){w.st[0][i], w.st[1][i], w.st[2][i]};
-                    r->d = (Vec3){w.st[3][i], w.st[4][i], w.st[5][i]};
-                }
-                const size_t nbytes = np / 8 + 1;
-                for (size_t tx = 0; tx < ntx; ++tx) {
-                    const size_t off_rays = (tx * nb + (b + 1)) * np;
-                    const size_t off_act = (tx * nb + (b + 1)) * nbytes;
-                    memcpy(scat_rays->rays + off_rays, w.cur_rays + tx * np, np * sizeof(Ray));
-                    uint8_t *dst = scat_rays->rays_active + off_act;
-                    memcpy(dst, w.next_active, nbytes);
-                    if (tx == 0 && ntx > 1)   /* Q12: tx1's first bits are still last bounce's */
-                        for (size_t bitp = np; bitp < 8 * nbytes; ++bitp) {
-                            uint8_t m = (uint8_t)(1u << (bitp % 8));
-                            dst[bitp / 8] = (uint8_t)((dst[bitp / 8] & ~m) | (w.active[bitp / 8] & m));
-                        }
-                }
-                uint8_t *sw = w.active; w.active = w.next_active; w.next_active = sw;
-            }
-        }
-        t_rb += hrt_now_s() - t0;
-    }
-
-    st.t_device_s = t_dev;
-    st.t_readback_s = t_rb;
-    st.t_total_s = hrt_now_s() - t_begin;
-    if (stats) *stats = st;
-    rc = HRT_OK;
+    st.num_devices = D;
+    st.num_batches = G;
 
 done:
-    work_free(&w);
-    hrt_problem_destroy(prob);
+    for (int d = 0; d < D; ++d) {
+        if (d > 0 && ctx[d].w.h_dirs == ctx[0].w.h_dirs) ctx[d].w.h_dirs = NULL;   /* shared table */
+        if (ctx[d].rc == HRT_OK && rc) ctx[d].rc = rc;
+    }
+    for (int d = D - 1; d >= 0; --d) {
+        if (ctx[d].w.d_ws || ctx[d].w.ray) worker_release(&ctx[d]);
+        hrt_problem_destroy(ctx[d].prob);
+    }
+    if (pool_taken) {
+        pthread_mutex_lock(&g_pool_lock);
+        g_pool_busy = 0;
+        pthread_mutex_unlock(&g_pool_lock);
+    }
+    free(ctx);
+    st.t_total_s = hrt_now_s() - t_begin;
+    if (!rc && stats) *stats = st;
     return rc;
 }
 

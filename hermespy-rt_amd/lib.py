@@ -54,7 +54,8 @@ class Stats(C.Structure):
                 ("records_unblocked", C.c_uint64), ("tests", C.c_uint64),
                 ("t_setup_s", C.c_double), ("t_launch_dirs_s", C.c_double),
                 ("t_device_s", C.c_double), ("t_readback_s", C.c_double),
-                ("t_total_s", C.c_double), ("device", C.c_int)]
+                ("t_total_s", C.c_double), ("device", C.c_int), ("num_devices", C.c_int),
+                ("num_batches", C.c_uint32)]
 
 
 class HrtError(RuntimeError):

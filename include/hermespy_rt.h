@@ -104,8 +104,11 @@ typedef struct {
     uint64_t records_unblocked;
     uint64_t tests;           /* algorithmic ray-triangle tests of the brute-force reference:
                                  nrx*ntx*T + sum_b T*(live[b] + nrx*hits[b]) */
-    double t_setup_s, t_launch_dirs_s, t_device_s, t_readback_s, t_total_s;
-    int device;
+    double t_setup_s, t_launch_dirs_s, t_device_s, t_readback_s, t_total_s;   /* device / readback: the
+                                 slowest device's */
+    int device;               /* the first device used */
+    int num_devices;          /* devices the batches were dealt to (HRT_DEVICES) */
+    uint32_t num_batches;     /* round-robin shards of the launch set the call was cut into */
 } hrt_stats;
 
 /* Same as compute_paths() but returns 0 / a negative HRT_E_* code instead of exiting, takes

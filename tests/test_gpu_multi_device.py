@@ -1,0 +1,67 @@
+"""Multi-GPU inside the C ABI (the reference's contract is one blocking call with
+caller-owned outputs, inc/compute_paths.h:59-74): HRT_DEVICES deals the round-robin batches of the
+launch set to one host thread per device, each copying its records into the caller's dense arrays.
+On the one-GPU test box the devices are LOGICAL (the same HIP device several times): the code path
+-- threads, per-device problem copies, workspaces, streams, staging, disjoint dense writes -- is the
+multi-GPU one.  Every output array must equal the single-device result and the oracle, bit for bit."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r"""
+import sys
+sys.path.insert(0, %(repo)r)
+import numpy as np
+from hermespy_rt_amd import abi, lib
+from oracle import oracle
+from tests import configs as K
+from tests.parity import compare_dense
+L = lib.load()
+for c, rays in ((K.small(K.C3, 70000), False), (K.small(K.C4_DOPPLER, 30001), False), (K.small(K.C5, 9000), False),
+                (K.small(K.C3_DOPPLER, 20000), True)):
+    st = lib.Stats()
+    got = abi.run_compute_paths(L, *K.args(c), with_rays=rays, stats=st)
+    ref = oracle.compute_paths(*K.args(c))
+    if not rays:   # without RaysInfo the ray arrays keep their sentinels in `got`
+        for k in ("los_rays", "los_active", "scat_rays", "scat_active"):
+            ref[k] = got[k]
+    s = compare_dense(got, ref)
+    assert all(v == 0 for v in s.values()), s
+    want = 1 if rays else min(%(want)d, (c["num_paths"] + 4095) // 4096)   # a batch is at least one 4096-path granule
+    assert st.num_devices == want, (st.num_devices, want, st.num_batches)
+    assert st.num_batches %% st.num_devices == 0
+    assert [int(st.live[i]) for i in range(c["num_bounces"] + 1)] == [int(x) for x in ref["extras"]["live"]]
+print("MULTI_OK")
+"""
+
+
+@pytest.mark.parametrize("devices,want", [("0", 1), ("0,0", 2), ("0,0,0,0", 4), ("0,0,0", 3)])
+def test_logical_devices_equal_the_oracle(devices, want):
+    env = dict(os.environ, HRT_DEVICES=devices)
+    p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO, want=want)], env=env, capture_output=True, text=True)
+    assert p.returncode == 0 and "MULTI_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_warm_calls_reuse_pooled_buffers(product_lib):
+    """second and third call (other endpoints, then a smaller launch set) through the buffer pool;
+    then hrt_cache_clear() and once more"""
+    from hermespy_rt_amd import abi
+    from oracle import oracle
+    from . import configs as K
+    from .parity import compare_dense
+    a = K.small(K.C3, 40000)
+    a2 = dict(a, rx_pos=[[-12, 1.0, 1.5], [8, -1.5, 2.0], [30, 0, 1.5], [45, 2, 3]])
+    b = K.small(K.C4_DOPPLER, 9001)
+    for c in (a, a2, b, a):
+        got = abi.run_compute_paths(product_lib, *K.args(c))
+        st = compare_dense(got, oracle.compute_paths(*K.args(c)))
+        assert all(v == 0 for v in st.values()), st
+    product_lib.hrt_cache_clear()
+    got = abi.run_compute_paths(product_lib, *K.args(b))
+    st = compare_dense(got, oracle.compute_paths(*K.args(b)))
+    assert all(v == 0 for v in st.values()), st
