@@ -95,7 +95,7 @@ typedef struct {
     uint64_t *mask;
     float *rec2[HRT_REC_FIELDS];   /* second staging set: the copy of the next (bounce, rx) block */
     uint64_t *mask2;              /* overlaps the dense scatter of the current one */
-    void *copy_stream;
+    void *copy_stream, *copy_stream2;   /* two streams: two DMA engines (one engine moves ~28 GB/s) */
     Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
     uint8_t *active, *next_active;
     float *dirs_batch;      /* gathered launch directions of one batch */
@@ -160,6 +160,10 @@ static void work_free(work_t *w)
         hrt_hip_stream_sync(w->copy_stream);
         hrt_hip_stream_destroy(w->copy_stream);
     }
+    if (w->copy_stream2) {
+        hrt_hip_stream_sync(w->copy_stream2);
+        hrt_hip_stream_destroy(w->copy_stream2);
+    }
     if (w->d_dirs) hrt_device_free(w->device, w->d_dirs);
     if (w->d_order) hrt_device_free(w->device, w->d_order);
     free(w->h_order);
@@ -187,29 +191,75 @@ typedef struct {
     uint64_t unblocked[HRT_MAX_SCATTER_THREADS];
 } scatter_ctx;
 
-/* records of (bounce b, rx) -> dense slots ((rx*ntx+tx)*nb+b)*np+p   (src/compute_paths.c:674) */
+/* records of (bounce b, rx) -> dense slots ((rx*ntx+tx)*nb+b)*np+p   (src/compute_paths.c:674).
+ * The index arithmetic is the hot part of the host side (27 M records on C3): the 64-bit
+ * divisions of the general shard mapping cost more than the nine stores, so the two common cases
+ * -- one TX, and one batch or the default power-of-two granule -- are done with shifts. */
 static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
 {
     scatter_ctx *c = (scatter_ctx *)vctx;
     ChannelInfo *scat = c->scat;
     uint64_t unb = 0;
+    const hrt_shard *s = c->s;
+    const uint32_t ch = s->chunk ? s->chunk : 4096u;
+    const int ch_pow2 = (ch & (ch - 1u)) == 0u;
+    int sh = 0;
+    while ((1u << sh) < ch) ++sh;
+    const uint64_t count = s->count, rank = s->rank, n_loc = c->n_loc;
+    float *const a0 = scat->a_te_re, *const a1 = scat->a_te_im, *const a2 = scat->a_tm_re, *const a3 = scat->a_tm_im;
+    float *const tau = scat->tau, *const fs = scat->freq_shift;
+    Vec3 *const drx = scat->directions_rx;
+    const float *r0 = c->rec[HRT_REC_A_TE_RE], *r1 = c->rec[HRT_REC_A_TE_IM], *r2 = c->rec[HRT_REC_A_TM_RE],
+                *r3 = c->rec[HRT_REC_A_TM_IM], *r4 = c->rec[HRT_REC_TAU], *r5 = c->rec[HRT_REC_DIRX],
+                *r6 = c->rec[HRT_REC_DIRY], *r7 = c->rec[HRT_REC_DIRZ], *r8 = c->rec[HRT_REC_DFS];
     for (uint64_t i = c->i_base + i0; i < c->i_base + i1; ++i) {
-        const uint32_t ql = c->ray[i];
-        const size_t tx = ql / c->n_loc;
-        const uint64_t p = hrt_shard_global_path(c->s, ql - tx * c->n_loc);
+        uint64_t ql = c->ray[i];
+        size_t tx = 0;
+        if (c->ntx > 1) { tx = ql / n_loc; ql -= tx * n_loc; }
+        uint64_t p;
+        if (count == 1) p = ql;
+        else if (ch_pow2) p = (((ql >> sh) * count + rank) << sh) + (ql & (ch - 1u));
+        else p = ((ql / ch) * count + rank) * ch + ql % ch;
         const size_t off = ((c->rx * c->ntx + tx) * c->nb + c->b) * c->np + p;
-        scat->a_te_re[off] = c->rec[HRT_REC_A_TE_RE][i];
-        scat->a_te_im[off] = c->rec[HRT_REC_A_TE_IM][i];
-        scat->a_tm_re[off] = c->rec[HRT_REC_A_TM_RE][i];
-        scat->a_tm_im[off] = c->rec[HRT_REC_A_TM_IM][i];
-        scat->tau[off] = c->rec[HRT_REC_TAU][i];
+        a0[off] = r0[i];
+        a1[off] = r1[i];
+        a2[off] = r2[i];
+        a3[off] = r3[i];
+        tau[off] = r4[i];
         if ((c->mask[i >> 6] >> (i & 63)) & 1u) {
-            scat->directions_rx[off] = (Vec3){c->rec[HRT_REC_DIRX][i], c->rec[HRT_REC_DIRY][i], c->rec[HRT_REC_DIRZ][i]};
-            scat->freq_shift[off] -= c->rec[HRT_REC_DFS][i];       /* :722 */
+            drx[off] = (Vec3){r5[i], r6[i], r7[i]};
+            fs[off] -= r8[i];       /* :722 */
             ++unb;
         }
     }
     c->unblocked[tid] += unb;
+}
+
+/* Q10 adds of one TX run (distinct slots: one per ray), see run_batch */
+typedef struct {
+    const hrt_shard *s;
+    const uint32_t *ray, *tri;
+    const float *h_mesh;
+    const uint32_t *tri_mesh;
+    float *fs_tx;            /* freq_shift + tx * np */
+    float dop_mult;
+    uint64_t ray_base, i_base;
+} q10_ctx;
+static void q10_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    (void)tid;
+    q10_ctx *c = (q10_ctx *)vctx;
+    const hrt_shard *s = c->s;
+    const uint32_t ch = s->chunk ? s->chunk : 4096u;
+    const uint64_t count = s->count, rank = s->rank;
+    for (uint64_t i = c->i_base + i0; i < c->i_base + i1; ++i) {
+        const uint64_t ql = c->ray[i] - c->ray_base;
+        const uint64_t p = (count == 1) ? ql : ((ql / ch) * count + rank) * ch + ql % ch;
+        const float *mv = c->h_mesh + (size_t)c->tri_mesh[c->tri[i]] * HRT_MESH_FLOATS;
+        const float zero = 0.f;   /* d - d with finite d */
+        float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
+        c->fs_tx[p] += z * c->dop_mult;
+    }
 }
 
 /* ---- devices --------------------------------------------------------------------------------
@@ -342,6 +392,7 @@ static int worker_alloc(dev_ctx *c)
     for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w->rec2[k], cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask2, cap / 64 * 8 + 8) == 0;
     ok &= hrt_hip_stream_create(&w->copy_stream) == 0;
+    ok &= hrt_hip_stream_create(&w->copy_stream2) == 0;
     if (!ok) return hrt_fail(HRT_E_NOMEM, "out of host memory (page-locked staging)");
     c->cap_alloc = cap; c->ws_alloc = L.total_bytes; c->dirs_rows_alloc = n_loc_max + 64;
     return HRT_OK;
@@ -358,6 +409,7 @@ static void worker_release(dev_ctx *c)
     const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (2 + 2 * HRT_REC_FIELDS + 6);
     if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 6ull << 30)) {
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
+        if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);
         pool_slot *ps = &g_pool[c->index];
         ps->valid = 1; ps->device = c->device; ps->with_rays = w->st[0] != NULL;
         ps->cap = c->cap_alloc; ps->ws_bytes = c->ws_alloc; ps->dirs_rows = c->dirs_rows_alloc;
@@ -498,10 +550,11 @@ static int run_batch(dev_ctx *c, uint32_t g)
         const uint64_t i0_ = (I0), n_ = (I1) - (I0), w0_ = (I0) / 64, w1_ = ((I1) + 63) / 64;         \
         int e_ = 0;                                                                                  \
         for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
-            e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w->d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, w->copy_stream); \
+            e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w->d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, \
+                                   (k & 1) ? w->copy_stream2 : w->copy_stream);                      \
         if (!e_)                                                                                     \
             e_ = hrt_hip_d2h_async((SET_MASK) + w0_, (const uint8_t *)w->d_ws + L.off_masks + (((uint64_t)b * nrx + (RX)) * (L.cap / 64) + w0_) * 8, \
-                                   (w1_ - w0_) * 8, w->copy_stream);                                 \
+                                   (w1_ - w0_) * 8, w->copy_stream2);                                \
         if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
     } while (0)
         /* runs of equal TX in the hit list (at most ntx) */
@@ -530,12 +583,10 @@ static int run_batch(dev_ctx *c, uint32_t g)
         for (uint64_t run = 0; run < nruns; ++run) {
             const uint64_t r0 = w->run_start[run], r1 = w->run_start[run + 1];
             const size_t txr = w->run_tx[run];
-            for (uint64_t i = r0; i < r1; ++i) {
-                const uint64_t p = hrt_shard_global_path(&s, w->ray[i] - txr * n_loc);
-                const float *mv = prob->h_mesh + (size_t)prob->h_tri_mesh[w->tri[i]] * HRT_MESH_FLOATS;
-                const float zero = 0.f;   /* d - d with finite d */
-                float z = (zero * mv[0] + zero * mv[1]) + zero * mv[2];
-                scat->freq_shift[txr * np + p] += z * prob->dop_mult;
+            {
+                q10_ctx qc = {&s, w->ray, w->tri, prob->h_mesh, prob->h_tri_mesh, scat->freq_shift + txr * np,
+                              prob->dop_mult, txr * n_loc, r0};
+                hrt_parallel_ranges(q10_range, &qc, r1 - r0, c->scatter_threads);
             }
             if (run == 0) FETCH_RX(0, w->rec, w->mask, r0, r1);
             for (size_t rx = 0; rx < nrx; ++rx) {
@@ -543,7 +594,8 @@ static int run_batch(dev_ctx *c, uint32_t g)
                 float *const *cur_rec = (slot & 1) ? w->rec2 : w->rec;
                 const uint64_t *cur_mask = (slot & 1) ? w->mask2 : w->mask;
                 {
-                    const int e = hrt_hip_stream_sync(w->copy_stream);   /* block rx has landed */
+                    int e = hrt_hip_stream_sync(w->copy_stream);   /* block rx has landed */
+                    if (!e) e = hrt_hip_stream_sync(w->copy_stream2);
                     if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
                 }
                 if (rx + 1 < nrx || run + 1 < nruns) {   /* next block: rx+1, or rx 0 of the next run */
@@ -559,7 +611,8 @@ static int run_batch(dev_ctx *c, uint32_t g)
                     sc.s = &s; sc.ray = w->ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
                     sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
                     sc.i_base = r0;
-                    hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
+                    if (!env_int("HRT_DEBUG_NO_SCATTER", 0))   /* timing experiments: copies only */
+                        hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
                     for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st->records_unblocked += sc.unblocked[t];
                 }
             }

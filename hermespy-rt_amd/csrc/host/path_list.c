@@ -143,7 +143,10 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     st.t_setup_s = hrt_now_s() - t_begin;
 
     void *d_ws = NULL, *d_dirs = NULL, *d_order = NULL;
-    float *h_dirs = NULL, *h_field[HRT_REC_FIELDS] = {0}, *h_fs0 = NULL;
+    float *h_dirs = NULL, *h_field[HRT_REC_FIELDS] = {0}, *h_field2[HRT_REC_FIELDS] = {0}, *h_fs0 = NULL;
+    uint64_t *h_mask2 = NULL;
+    void *copy_stream = NULL;
+    const int host_launch = (int)pl_env_u64("HRT_HOST_LAUNCH", 0);
     uint32_t *h_order = NULL, *h_ray = NULL, *h_tri = NULL, *h_counts = NULL;
     uint64_t *h_mask = NULL;
     uint64_t cap_out = 0;
@@ -188,6 +191,9 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         ok &= hrt_hip_host_malloc((void **)&h_fs0, cap * 4) == 0;
         ok &= hrt_hip_host_malloc((void **)&h_mask, cap / 64 * 8 + 8) == 0;
         for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&h_field[k], cap * 4) == 0;
+        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&h_field2[k], cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&h_mask2, cap / 64 * 8 + 8) == 0;
+        ok &= hrt_hip_stream_create(&copy_stream) == 0;
         out->los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
         if (!ok || !out->los) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
     }
@@ -205,15 +211,22 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         if (n_loc == 0) continue;
         if ((rc = hrt_layout_query(prob, &s, &L))) goto done;
         double t0 = hrt_now_s();
-        if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, h_dirs, h_order))) {
-            if ((rc = hrt_launch_dirs_host(&s, h_dirs, 0))) goto done;
-            if ((rc = hrt_launch_order_host(&s, h_dirs, h_order))) goto done;
-            if (G == 1) hrt_launch_cache_put(np, h_dirs, h_order);
+        if (host_launch) {
+            if (!(G == 1 && hrt_launch_cache_enabled(np) && hrt_launch_cache_get(np, h_dirs, h_order))) {
+                if ((rc = hrt_launch_dirs_host(&s, h_dirs, 0))) goto done;
+                if ((rc = hrt_launch_order_host(&s, h_dirs, h_order))) goto done;
+                if (G == 1) hrt_launch_cache_put(np, h_dirs, h_order);
+            }
+            t_dirs += hrt_now_s() - t0;
+            t0 = hrt_now_s();
+            if ((rc = hrt_device_upload(device, d_dirs, h_dirs, n_loc * 12))) goto done;
+            if ((rc = hrt_device_upload(device, d_order, h_order, n_loc * 4))) goto done;
+        } else {   /* launch tables on the device (the default, as in compute_paths) */
+            if ((rc = hrt_launch_dirs_device(&s, (float *)d_dirs, device, NULL, NULL))) goto done;
+            if ((rc = hrt_launch_order_device(&s, (uint32_t *)d_order, device, NULL))) goto done;
+            t_dirs += hrt_now_s() - t0;
+            t0 = hrt_now_s();
         }
-        t_dirs += hrt_now_s() - t0;
-        t0 = hrt_now_s();
-        if ((rc = hrt_device_upload(device, d_dirs, h_dirs, n_loc * 12))) goto done;
-        if ((rc = hrt_device_upload(device, d_order, h_order, n_loc * 4))) goto done;
         if ((rc = hrt_trace(prob, &s, (const float *)d_dirs, (const uint32_t *)d_order, d_ws,
                             L.total_bytes, NULL, NULL))) goto done;
         if ((rc = hrt_device_sync(device, NULL))) goto done;
@@ -245,15 +258,33 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             DLP(h_ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
             DLP(h_tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
             DLP(h_fs0, hb + (uint64_t)HRT_HIT_FS0 * L.cap * 4, H * 4);
+#define FETCH_PL(RX, SET, MASK)                                                                   \
+    do {                                                                                          \
+        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
+        int e_ = 0;                                                                               \
+        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                           \
+            e_ = hrt_hip_d2h_async((SET)[k], (const uint8_t *)d_ws + rb_ + (uint64_t)k * L.cap * 4, H * 4, copy_stream); \
+        if (!e_) e_ = hrt_hip_d2h_async((MASK), (const uint8_t *)d_ws + L.off_masks + ((uint64_t)b * nrx + (RX)) * (L.cap / 64) * 8, \
+                                        (H + 63) / 64 * 8, copy_stream);                          \
+        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }    \
+    } while (0)
+            FETCH_PL(0, h_field, h_mask);
             for (size_t rx = 0; rx < nrx; ++rx) {
-                const uint64_t rb = L.off_recs + b * L.rec_block_bytes + (uint64_t)rx * HRT_REC_FIELDS * L.cap * 4;
-                for (int k = 0; k < HRT_REC_FIELDS; ++k) DLP(h_field[k], rb + (uint64_t)k * L.cap * 4, H * 4);
-                DLP(h_mask, L.off_masks + ((uint64_t)b * nrx + rx) * (L.cap / 64) * 8, (H + 63) / 64 * 8);
+                float *const *cur_field = (rx & 1) ? h_field2 : h_field;
+                const uint64_t *cur_mask = (rx & 1) ? h_mask2 : h_mask;
+                {
+                    const int e = hrt_hip_stream_sync(copy_stream);   /* block rx has landed */
+                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
+                }
+                if (rx + 1 < nrx) {   /* the copy of the next block runs while this one is written out */
+                    if (rx & 1) FETCH_PL(rx + 1, h_field, h_mask);
+                    else FETCH_PL(rx + 1, h_field2, h_mask2);
+                }
                 {
                     fill_ctx fc;
                     memset(&fc, 0, sizeof fc);
                     fc.out = out; fc.s = &s; fc.prob = prob; fc.ray = h_ray; fc.tri = h_tri; fc.fs0 = h_fs0;
-                    fc.field = h_field; fc.mask = h_mask; fc.n_loc = n_loc; fc.base = out->num;
+                    fc.field = cur_field; fc.mask = cur_mask; fc.n_loc = n_loc; fc.base = out->num;
                     fc.rx = (uint32_t)rx; fc.bounce = (uint32_t)b; fc.include_blocked = include_blocked;
                     int nt = threads;
                     if ((uint64_t)nt > H / 65536 + 1) nt = (int)(H / 65536 + 1);
@@ -262,7 +293,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                         /* ranges on 64-entry boundaries, so that no mask word is shared */
                         fc.i0[t] = (H * (uint64_t)t / (uint64_t)nt) & ~63ull;
                         fc.i1[t] = (t + 1 == nt) ? H : ((H * (uint64_t)(t + 1) / (uint64_t)nt) & ~63ull);
-                        const uint64_t u = count_bits(h_mask, fc.i0[t], fc.i1[t]);
+                        const uint64_t u = count_bits(cur_mask, fc.i0[t], fc.i1[t]);
                         fc.start[t] = total;
                         total += include_blocked ? fc.i1[t] - fc.i0[t] : u;
                         unb += u;
@@ -276,6 +307,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         }
         t_rb += hrt_now_s() - t0;
     }
+#undef FETCH_PL
 #undef DLP
     st.t_launch_dirs_s = t_dirs;
     st.t_device_s = t_dev;
@@ -289,8 +321,10 @@ done:
     if (d_dirs) hrt_device_free(device, d_dirs);
     if (d_order) hrt_device_free(device, d_order);
     free(h_dirs); free(h_order); free(h_counts);
+    if (copy_stream) { hrt_hip_stream_sync(copy_stream); hrt_hip_stream_destroy(copy_stream); }
     hrt_hip_host_free(h_ray); hrt_hip_host_free(h_tri); hrt_hip_host_free(h_fs0); hrt_hip_host_free(h_mask);
-    for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(h_field[k]);
+    hrt_hip_host_free(h_mask2);
+    for (int k = 0; k < HRT_REC_FIELDS; ++k) { hrt_hip_host_free(h_field[k]); hrt_hip_host_free(h_field2[k]); }
     hrt_problem_destroy(prob);
     if (rc != HRT_OK) hrt_path_list_free(out);
     return rc;

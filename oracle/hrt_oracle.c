@@ -125,6 +125,13 @@ typedef struct {
     float *eta_table;     /* [17][12] MaterialPrecomputed rows, reference field order */
     float *normals;       /* [num_tri][3] */
     float *launch_dirs;   /* [np][3] */
+    /* compact subset (test infrastructure for launch sets whose dense arrays do not fit the host,
+     * C5 at 8 x 8 x 8 x 8M): every array indexed by the path -- scatter outputs, hit_tri, hit_theta
+     * -- has extent npo = number of subset paths and slot (p - p_begin) / p_stride instead of np
+     * and p; freq_shift is the record's own value (launch term minus the record's: the dense
+     * array's value for one TX, without the reference's replication quirks Q9/Q10); RaysInfo
+     * snapshots are not taken (scat_rays may be NULL). */
+    int compact;
 } hrt_oracle_opts;
 
 /* src/compute_paths.c:125-132 field order */
@@ -298,6 +305,9 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
     uint64_t p_begin = 0, p_end = np, p_stride = 1;
     if (opt && opt->p_stride) { p_begin = opt->p_begin; p_end = opt->p_end; p_stride = opt->p_stride; }
     if (p_end > np) p_end = np;
+    const int compact = opt && opt->compact;
+    const size_t npo = compact ? (size_t)((p_end - p_begin + p_stride - 1) / p_stride) : np;
+#define PO(p) (compact ? (size_t)(((p) - p_begin) / p_stride) : (size_t)(p))
 #ifdef _OPENMP
     int nthr = (opt && opt->num_threads > 0) ? opt->num_threads : omp_get_max_threads();
 #endif
@@ -351,7 +361,8 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
             st3(s + 3, dirs[p]);
             s[6] = 1.f; s[7] = 0.f; s[8] = 1.f; s[9] = 0.f; s[10] = 0.f;
         }
-    for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = active[i] = 0xff;
+    for (size_t i = 0; i < nq / 8 + 1; ++i) active[i] = 0xff;
+    if (!compact) for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
 
     /* ---- multipliers (:483-488) ---- */
     float f_hz = (float)((double)f_ghz * 1e9);
@@ -359,15 +370,25 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
     float dop_mult = f_hz / HRT_C_F;
 
     /* ---- scatter Doppler launch term and its replication (:494-508, quirk Q9) ---- */
-    for (size_t tx = 0; tx < ntx; ++tx)
-        for (size_t p = 0; p < np; ++p) {
-            float v = dot3(ld3(tx_vel + 3 * tx), dirs[p]);
-            scat->freq_shift[tx * np * nb + p] = v * dop_mult;
-        }
-    for (size_t b = 1; b < nb; ++b)
-        memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
-    for (size_t rx = 1; rx < nrx; ++rx)
-        memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
+    if (compact) {
+        for (size_t rx = 0; rx < nrx; ++rx)
+            for (size_t tx = 0; tx < ntx; ++tx)
+                for (size_t b = 0; b < nb; ++b)
+                    for (uint64_t p = p_begin; p < p_end; p += p_stride) {
+                        float v = dot3(ld3(tx_vel + 3 * tx), dirs[p]);
+                        scat->freq_shift[((rx * ntx + tx) * nb + b) * npo + PO(p)] = v * dop_mult;
+                    }
+    } else {
+        for (size_t tx = 0; tx < ntx; ++tx)
+            for (size_t p = 0; p < np; ++p) {
+                float v = dot3(ld3(tx_vel + 3 * tx), dirs[p]);
+                scat->freq_shift[tx * np * nb + p] = v * dop_mult;
+            }
+        for (size_t b = 1; b < nb; ++b)
+            memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
+        for (size_t rx = 1; rx < nrx; ++rx)
+            memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
+    }
 
     /* algorithmic count: the LoS pass is priced at nrx*ntx*T */
     uint64_t n_tests = (uint64_t)nrx * ntx * T;
@@ -412,7 +433,8 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
         }
 
     /* ---- launch snapshot (:589) ---- */
-    for (size_t q = 0; q < nq; ++q) memcpy(scat_rays->rays + 6 * q, st + 11 * q, 6 * sizeof(float));
+    if (!compact)
+        for (size_t q = 0; q < nq; ++q) memcpy(scat_rays->rays + 6 * q, st + 11 * q, 6 * sizeof(float));
 
     /* ---- live lists per tx, in path order ---- */
     for (size_t tx = 0; tx < ntx; ++tx) {
@@ -421,7 +443,7 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
         live_cnt[tx] = n;
     }
     if (opt && opt->live) memset(opt->live, 0, (nb + 1) * sizeof(uint64_t));
-    if (opt && opt->hit_tri) memset(opt->hit_tri, 0xff, nb * nq * sizeof(uint32_t));
+    if (opt && opt->hit_tri) memset(opt->hit_tri, 0xff, nb * (compact ? ntx * npo : nq) * sizeof(uint32_t));
 
     /* rays outside the processed subset are "never live": clear their bits so that the
      * active masks equal a run in which they all missed at bounce 0.  (Full runs: no-op.) */
@@ -480,7 +502,7 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
                 /* scatter to every rx IN ORDER, carrying theta (Q7)           :671-723 */
                 float theta = h.theta;
                 for (size_t rx = 0; rx < nrx; ++rx) {
-                    const size_t off = ((rx * ntx + tx) * nb + b) * np + p;   /* :674 */
+                    const size_t off = ((rx * ntx + tx) * nb + b) * npo + PO(p);   /* :674 */
                     v3 w = sub3(ld3(rx_pos + 3 * rx), o);
                     float d2rx = sqrtf(dot3(w, w));
                     w = unit3(w);
@@ -521,12 +543,13 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
                     active[q / 8] &= (uint8_t)~(1u << (q % 8));               /* :617 */
                     continue;
                 }
-                if (opt && opt->hit_tri) opt->hit_tri[b * nq + q] = hits[i].tri;
-                if (opt && opt->hit_theta) opt->hit_theta[b * nq + q] = hits[i].theta;
-                scat->freq_shift[q] += dfs[i * (nrx + 1) + nrx];              /* :664, Q10 */
+                const size_t qo = compact ? (b * ntx + tx) * npo + PO(p) : b * nq + q;
+                if (opt && opt->hit_tri) opt->hit_tri[qo] = hits[i].tri;
+                if (opt && opt->hit_theta) opt->hit_theta[qo] = hits[i].theta;
+                if (!compact) scat->freq_shift[q] += dfs[i * (nrx + 1) + nrx];   /* :664, Q10 */
                 for (size_t rx = 0; rx < nrx; ++rx)
                     if (unblocked[i * nrx + rx]) {
-                        const size_t off = ((rx * ntx + tx) * nb + b) * np + p;
+                        const size_t off = ((rx * ntx + tx) * nb + b) * npo + PO(p);
                         scat->freq_shift[off] -= dfs[i * (nrx + 1) + rx];     /* :722 */
                     }
                 nx[n_next++] = (uint32_t)p;
@@ -536,15 +559,18 @@ int hrt_oracle_compute_paths(const hrt_oracle_scene *sc,
             if (opt && opt->live && b + 1 == nb) opt->live[nb] += n_hit;
 
             /* snapshots (:732-743, quirks Q11/Q12/Q14: stride nb, mask always from byte 0) */
-            size_t off_rays = (tx * nb + (b + 1)) * np;
-            size_t off_act = (tx * nb + (b + 1)) * (np / 8 + 1);
-            for (size_t p = 0; p < np; ++p)
-                memcpy(scat_rays->rays + 6 * (off_rays + p), st + 11 * (tx * np + p),
-                       6 * sizeof(float));
-            memcpy(scat_rays->rays_active + off_act, active, np / 8 + 1);
+            if (!compact) {
+                size_t off_rays = (tx * nb + (b + 1)) * np;
+                size_t off_act = (tx * nb + (b + 1)) * (np / 8 + 1);
+                for (size_t p = 0; p < np; ++p)
+                    memcpy(scat_rays->rays + 6 * (off_rays + p), st + 11 * (tx * np + p),
+                           6 * sizeof(float));
+                memcpy(scat_rays->rays_active + off_act, active, np / 8 + 1);
+            }
         }
     }
     if (opt && opt->tests) *opt->tests = n_tests;
+#undef PO
 
     free(tris); free(dirs); free(st); free(active); free(live); free(hits); free(dfs);
     free(unblocked); free(live_tx); free(live_cnt);

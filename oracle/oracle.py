@@ -40,7 +40,7 @@ class _Opts(C.Structure):
     _fields_ = [("p_begin", C.c_uint64), ("p_end", C.c_uint64), ("p_stride", C.c_uint64),
                 ("num_threads", C.c_int), ("hit_tri", _u32p), ("hit_theta", _f32p),
                 ("live", _u64p), ("tests", _u64p), ("eta_table", _f32p), ("normals", _f32p),
-                ("launch_dirs", _f32p)]
+                ("launch_dirs", _f32p), ("compact", C.c_int)]
 
 
 def build(force=False):
@@ -207,6 +207,64 @@ def compute_paths(scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths, 
         ex["tri_face"] = flat["tri_face"]
         res["extras"] = ex
     return res
+
+
+def compute_paths_subset(scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths, num_bounces,
+                         subset, num_threads=0):
+    """The oracle on a strided subset (p_begin, p_end, p_stride) of a launch set whose dense arrays
+    would not fit the host (C5 at full size): arrays of extent n_sub = number of subset paths
+    instead of num_paths, slot k <-> path p_begin + k * p_stride.  Returns dict(paths [n_sub],
+    scat {a_*, tau, freq_shift: [nrx, ntx, nb, n_sub]; directions_rx [..., 3]} with sentinels in the
+    slots the reference does not write, hit_tri / hit_theta [nb, ntx, n_sub], live [nb+1]).
+    freq_shift is the record's own value (launch term minus the record's)."""
+    L = lib()
+    flat = flatten(read_hrt(scene_path))
+    T = flat["tri_vtx"].shape[0]
+    rx_pos = np.ascontiguousarray(np.asarray(rx_pos, np.float32).reshape(-1, 3))
+    tx_pos = np.ascontiguousarray(np.asarray(tx_pos, np.float32).reshape(-1, 3))
+    nrx, ntx = rx_pos.shape[0], tx_pos.shape[0]
+    rx_vel = np.ascontiguousarray(np.asarray(rx_vel, np.float32).reshape(nrx, 3))
+    tx_vel = np.ascontiguousarray(np.asarray(tx_vel, np.float32).reshape(ntx, 3))
+    npth, nb = int(num_paths), int(num_bounces)
+    pb, pe, ps = [int(x) for x in subset]
+    pe = min(pe, npth)
+    paths = np.arange(pb, pe, ps, dtype=np.int64)
+    ns = len(paths)
+    sc = _Scene(len(flat["mesh_material"]), T, _p(flat["tri_vtx"]), _p(flat["tri_mesh"], _u32p),
+                _p(flat["mesh_material"], _u32p), _p(flat["mesh_velocity"]))
+
+    def chan(n):
+        d = dict(directions_rx=_sentinel(3 * n), directions_tx=_sentinel(3 * n),
+                 a_te_re=_sentinel(n), a_te_im=_sentinel(n), a_tm_re=_sentinel(n),
+                 a_tm_im=_sentinel(n), tau=_sentinel(n), freq_shift=_sentinel(n))
+        return d, _Chan(*[_p(d[k]) for k, _ in _Chan._fields_])
+
+    los, los_c = chan(nrx * ntx)
+    scat, scat_c = chan(nrx * ntx * nb * ns)
+    los_rays, los_active = _sentinel(6 * nrx * ntx), _sentinel(nrx * ntx // 8 + 1, np.uint8)
+    lr = _Rays(_p(los_rays), _p(los_active, _u8p))
+    sr = _Rays(None, None)
+    opts = _Opts()
+    opts.p_begin, opts.p_end, opts.p_stride = pb, pe, ps
+    opts.num_threads = int(num_threads)
+    opts.compact = 1
+    hit_tri = np.empty(nb * ntx * ns, np.uint32)
+    hit_theta = _sentinel(nb * ntx * ns)
+    live = np.zeros(nb + 1, np.uint64)
+    opts.hit_tri, opts.hit_theta, opts.live = _p(hit_tri, _u32p), _p(hit_theta), _p(live, _u64p)
+    rc = L.hrt_oracle_compute_paths(C.byref(sc), _p(rx_pos), _p(tx_pos), _p(rx_vel), _p(tx_vel),
+                                    C.c_float(f_ghz), nrx, ntx, npth, nb, C.byref(los_c),
+                                    C.byref(lr), C.byref(scat_c), C.byref(sr), C.byref(opts))
+    if rc != 0:
+        raise RuntimeError("hrt_oracle_compute_paths failed: %d" % rc)
+    shp = (nrx, ntx, nb, ns)
+    return dict(paths=paths,
+                scat={k: (v.reshape(*shp, 3) if k.startswith("directions") else v.reshape(shp))
+                      for k, v in scat.items()},
+                los={k: (v.reshape(nrx, ntx, 3) if k.startswith("directions") else v.reshape(nrx, ntx))
+                     for k, v in los.items()},
+                hit_tri=hit_tri.reshape(nb, ntx, ns), hit_theta=hit_theta.reshape(nb, ntx, ns), live=live,
+                tri_mesh=flat["tri_mesh"], tri_face=flat["tri_face"])
 
 
 LIBM_FN = dict(sinf=0, cosf=1, expf=2, acosf=3, incidence_angle=4)

@@ -45,7 +45,8 @@ SMALL = {
 }
 
 FULL = {"C1": K.C1, "C2": K.C2, "C3": K.C3, "C4_1M": K.small(K.C4, 1000000),
-        "C5_1M": K.small(K.C5, 1000000)}   # 8 TX x 8 RX x 8 bounces: ~25 GB of dense arrays, ~3 min
+        "C5_1M": K.small(K.C5, 1000000),   # 8 TX x 8 RX x 8 bounces: ~25 GB of dense arrays, ~3 min
+        "C4": K.C4}                        # BASELINE configs[3] at full size: 2 TX x 8 M rays x 6 bounces, ~12 GB
 
 M64 = (1 << 64) - 1
 
