@@ -66,6 +66,9 @@ struct hrt_problem {
     void *d_blob;
     const float *d_tri, *d_mesh, *d_mat, *d_rx_pos, *d_tx_pos, *d_rx_vel, *d_tx_vel;
     hrt_kaccel kaccel;           /* device pointers of the acceleration structure */
+    void *d_rxt;                 /* per-RX direction tables (device blob), or NULL */
+    hrt_krxt krxt;
+    uint64_t rxt_entries;        /* total list entries over all (rx, cell) */
 };
 
 /* error plumbing: set the thread's last-error text and return `code` */

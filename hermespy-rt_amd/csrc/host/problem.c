@@ -70,10 +70,144 @@ void hrt_problem_destroy(hrt_problem *p)
     if (p->d_blob) {
         hrt_hip_set_device(p->device);
         hrt_hip_free(p->d_blob);
+        if (p->d_rxt) hrt_hip_free(p->d_rxt);
     }
     free(p->h_tri); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
     hrt_accel_free(&p->accel);
     free(p);
+}
+
+/* ---- per-RX direction tables for the shadow rays (hrt_kparams.h, hrt_krxt) ----
+ * cube-map cell -> direction: the inverse of rxt_cell() in hrt_kernels.hip */
+static void rxt_dir(uint32_t f, double u, double v, double out[3])
+{
+    const uint32_t m = f % 3u;
+    const double sgn = f >= 3u ? -1.0 : 1.0;
+    double c[3];
+    c[m] = sgn;
+    c[(m + 1u) % 3u] = u * sgn;
+    c[(m + 2u) % 3u] = v * sgn;
+    const double l = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    out[0] = c[0] / l; out[1] = c[1] / l; out[2] = c[2] / l;
+}
+
+static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
+{
+    const uint32_t T = p->num_tri, nrx = p->num_rx;
+    const char *off_env = getenv("HRT_NO_RXT");
+    if (T == 0 || T > HRT_RXT_MAX_TRI || nrx > 64 || (off_env && *off_env && *off_env != '0')) return HRT_OK;
+    /* the ball every ray origin lies in: hit points are on triangles (+ 1e-4 along the new direction) */
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t j = 0; j < T; ++j) {
+        const float *r = p->h_tri + (size_t)j * HRT_TRI_FLOATS;
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) {
+                const double x = (double)r[k] + (v == 1 ? (double)r[3 + k] : (v == 2 ? (double)r[6 + k] : 0.0));
+                if (!isfinite(x)) return HRT_OK;   /* non-finite geometry: no tables, the whole table is walked */
+                if (x < lo[k]) lo[k] = x;
+                if (x > hi[k]) hi[k] = x;
+            }
+    }
+    const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    const double half = 0.5 * sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+    const float region_r = (float)(half * 1.01 + 0.01 + 1e-5 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2])));
+    if (!isfinite(region_r)) return HRT_OK;
+
+    const uint32_t NB = HRT_RXT_BINS, W = (T + 63u) / 64u;
+    float *bin_dir = (float *)malloc((size_t)NB * 4 * sizeof(float));
+    float *bin_cs = (float *)malloc((size_t)NB * 2 * sizeof(float));
+    float *ro_bin = (float *)malloc((size_t)nrx * sizeof(float));
+    uint64_t *masks = (uint64_t *)malloc((size_t)nrx * NB * W * 8);
+    uint32_t *off = (uint32_t *)malloc(((size_t)nrx * NB + 1) * 4);
+    int rc = HRT_OK, e;
+    void *d_tmp = NULL;
+    uint16_t *idx = NULL;
+    if (!bin_dir || !bin_cs || !ro_bin || !masks || !off) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
+    const double aq = asin((double)HRT_RXT_SIN_AQ);
+    for (uint32_t f = 0; f < 6; ++f)
+        for (uint32_t iv = 0; iv < HRT_RXT_N; ++iv)
+            for (uint32_t iu = 0; iu < HRT_RXT_N; ++iu) {
+                const uint32_t cell = (f * HRT_RXT_N + iv) * HRT_RXT_N + iu;
+                const double u0 = 2.0 * iu / HRT_RXT_N - 1.0, u1 = 2.0 * (iu + 1) / HRT_RXT_N - 1.0;
+                const double v0 = 2.0 * iv / HRT_RXT_N - 1.0, v1 = 2.0 * (iv + 1) / HRT_RXT_N - 1.0;
+                double ctr[3], q[3], cmin = 1.0;
+                rxt_dir(f, 0.5 * (u0 + u1), 0.5 * (v0 + v1), ctr);
+                const float cfl[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};   /* what the device gets */
+                const double fl = sqrt((double)cfl[0] * cfl[0] + (double)cfl[1] * cfl[1] + (double)cfl[2] * cfl[2]);
+                const double us[2] = {u0, u1}, vs[2] = {v0, v1};
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        rxt_dir(f, us[a], vs[b], q);
+                        const double cc = (q[0] * cfl[0] + q[1] * cfl[1] + q[2] * cfl[2]) / fl;
+                        if (cc < cmin) cmin = cc;
+                    }
+                /* cone of the cell + the widest packet served + rounding of the cell lookup */
+                const double ang = acos(cmin > 1 ? 1 : cmin) + aq + 3e-4;
+                bin_dir[4 * cell] = cfl[0]; bin_dir[4 * cell + 1] = cfl[1]; bin_dir[4 * cell + 2] = cfl[2]; bin_dir[4 * cell + 3] = 0.f;
+                float cs = (float)cos(ang), sn = (float)sin(ang);
+                if ((double)cs > cos(ang)) cs = nextafterf(cs, -1.f);      /* wider, never narrower */
+                if ((double)sn < sin(ang)) sn = nextafterf(sn, 2.f);
+                bin_cs[2 * cell] = cs; bin_cs[2 * cell + 1] = sn;
+            }
+    for (uint32_t r = 0; r < nrx; ++r) {
+        const double dx = (double)rx_pos[r].x - c[0], dy = (double)rx_pos[r].y - c[1], dz = (double)rx_pos[r].z - c[2];
+        const double lmax = (sqrt(dx * dx + dy * dy + dz * dz) + 2.0 * (double)region_r) * 1.001;
+        ro_bin[r] = (float)(8.0 * 0.5 * 1.1920928955078125e-07 * lmax * 1.001 + 2e-7);
+        if (!isfinite(ro_bin[r])) goto out;   /* an RX at infinity: no tables */
+    }
+    {
+        const uint64_t b_dir = (uint64_t)NB * 16, b_cs = (uint64_t)NB * 8, b_ro = (uint64_t)nrx * 4 + 252;
+        const uint64_t b_mask = (uint64_t)nrx * NB * W * 8;
+        if ((e = hrt_hip_malloc(&d_tmp, b_dir + b_cs + (b_ro & ~255ull) + 256 + b_mask))) { rc = hrt_fail_hip(e, "hipMalloc(rxt build)"); goto out; }
+        uint8_t *q = (uint8_t *)d_tmp;
+        float *d_dir = (float *)q; q += b_dir;
+        float *d_cs = (float *)q; q += b_cs;
+        float *d_ro = (float *)q; q += (b_ro & ~255ull) + 256;
+        unsigned long long *d_masks = (unsigned long long *)q;
+        if ((e = hrt_hip_h2d(d_dir, bin_dir, b_dir)) || (e = hrt_hip_h2d(d_cs, bin_cs, b_cs)) ||
+            (e = hrt_hip_h2d(d_ro, ro_bin, (uint64_t)nrx * 4))) { rc = hrt_fail_hip(e, "hipMemcpy(rxt build)"); goto out; }
+        if ((e = hrt_hip_rxt_build(p->d_tri, T, p->d_rx_pos, nrx, d_dir, d_cs, d_ro, cf[0], cf[1], cf[2], region_r,
+                                   d_masks, NULL))) { rc = hrt_fail_hip(e, "hrt_rxt_build_kernel"); goto out; }
+        if ((e = hrt_hip_stream_sync(NULL))) { rc = hrt_fail_hip(e, "hipStreamSynchronize"); goto out; }
+        if ((e = hrt_hip_d2h(masks, d_masks, b_mask))) { rc = hrt_fail_hip(e, "hipMemcpy D2H"); goto out; }
+    }
+    {
+        uint64_t total = 0;
+        for (uint64_t k = 0; k < (uint64_t)nrx * NB; ++k) {
+            off[k] = (uint32_t)total;
+            for (uint32_t w = 0; w < W; ++w) total += (uint64_t)__builtin_popcountll(masks[k * W + w]);
+        }
+        off[(uint64_t)nrx * NB] = (uint32_t)total;
+        if (total > 0xfffffff0ull) goto out;
+        idx = (uint16_t *)malloc((size_t)(total ? total : 1) * 2);
+        if (!idx) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
+        uint64_t n = 0;
+        for (uint64_t k = 0; k < (uint64_t)nrx * NB; ++k)
+            for (uint32_t w = 0; w < W; ++w) {
+                uint64_t m = masks[k * W + w];
+                while (m) {
+                    idx[n++] = (uint16_t)(w * 64u + (uint32_t)__builtin_ctzll(m));
+                    m &= m - 1;
+                }
+            }
+        const uint64_t b_ro = round_up((uint64_t)nrx * 4, 256), b_off = round_up(((uint64_t)nrx * NB + 1) * 4, 256);
+        const uint64_t b_idx = round_up((total ? total : 1) * 2, 256);
+        if ((e = hrt_hip_malloc(&p->d_rxt, b_ro + b_off + b_idx))) { p->d_rxt = NULL; rc = hrt_fail_hip(e, "hipMalloc(rxt)"); goto out; }
+        uint8_t *q = (uint8_t *)p->d_rxt;
+        if ((e = hrt_hip_h2d(q, ro_bin, (uint64_t)nrx * 4)) || (e = hrt_hip_h2d(q + b_ro, off, ((uint64_t)nrx * NB + 1) * 4)) ||
+            (total && (e = hrt_hip_h2d(q + b_ro + b_off, idx, total * 2)))) { rc = hrt_fail_hip(e, "hipMemcpy(rxt)"); goto out; }
+        p->krxt.enabled = 1u;
+        p->krxt.cx = cf[0]; p->krxt.cy = cf[1]; p->krxt.cz = cf[2]; p->krxt.region_r = region_r;
+        p->krxt.ro_bin = (const float *)q;
+        p->krxt.off = (const uint32_t *)(q + b_ro);
+        p->krxt.idx = (const uint16_t *)(q + b_ro + b_off);
+        p->rxt_entries = total;
+    }
+out:
+    if (d_tmp) hrt_hip_free(d_tmp);
+    free(bin_dir); free(bin_cs); free(ro_bin); free(masks); free(off); free(idx);
+    return rc;
 }
 
 int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
@@ -273,6 +407,10 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
     if (A->big) {
         ka->pl_index = (const uint32_t *)(b + offs[i_pli]);
         ka->pl_rec = (const float *)(b + offs[i_plr]);
+    }
+    {
+        const int rcx = rxt_build(p, rx_pos);
+        if (rcx) { hrt_problem_destroy(p); return rcx; }
     }
     *out = p;
     return HRT_OK;
@@ -721,6 +859,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.tri = p->d_tri; K.mesh = p->d_mesh; K.mat = p->d_mat;
     K.num_tri = p->num_tri; K.num_mesh = p->num_mesh;
     K.acc = p->kaccel;
+    K.rxt = p->krxt;
     K.rx_pos = p->d_rx_pos; K.tx_pos = p->d_tx_pos; K.rx_vel = p->d_rx_vel; K.tx_vel = p->d_tx_vel;
     K.num_rx = p->num_rx; K.num_tx = p->num_tx;
     K.fsl_mult = p->fsl_mult; K.dop_mult = p->dop_mult;

@@ -594,8 +594,27 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 // (and vice versa), which is what keeps the kernel's register allocation low.
 constexpr uint32_t kMaskRounds = 16;
 
+// cube-map cell of a direction (shared with the host builder, problem.c: rxt_cell_dir): face =
+// major axis + 3 * (major < 0), (u, v) = the two other components over the (signed) major one
+__device__ __forceinline__ uint32_t rxt_cell(F3 a)
+{
+    const float ax = fabsf(a.x), ay = fabsf(a.y), az = fabsf(a.z);
+    uint32_t m = 0u;
+    float major = a.x, c1 = a.y, c2 = a.z;
+    if (ay > ax && ay >= az) { m = 1u; major = a.y; c1 = a.z; c2 = a.x; }
+    else if (az > ax && az > ay) { m = 2u; major = a.z; c1 = a.x; c2 = a.y; }
+    const float inv = 1.f / major;
+    const float u = c1 * inv, v = c2 * inv;
+    int iu = (int)((u * 0.5f + 0.5f) * (float)HRT_RXT_N), iv = (int)((v * 0.5f + 0.5f) * (float)HRT_RXT_N);
+    iu = iu < 0 ? 0 : (iu > HRT_RXT_N - 1 ? HRT_RXT_N - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > HRT_RXT_N - 1 ? HRT_RXT_N - 1 : iv);
+    const uint32_t f = m + (major < 0.f ? 3u : 0u);
+    return (f * HRT_RXT_N + (uint32_t)iv) * HRT_RXT_N + (uint32_t)iu;
+}
+
 template <bool MULTI, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__restrict__ orig,
+                                                  const hrt_krxt &X, uint32_t rxk,
                                                   uint32_t num_tri, F3 o, F3 d,
                                                   bool valid, uint32_t lane, const Ball &B,
                                                   const bool shadow, F3 apex,
@@ -606,45 +625,52 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__
     uint32_t who = HRT_NO_HIT, who_o = 0u;
     const unsigned long long inval = HRT_BALLOT(!valid);
     if (inval == ~0ull) return {who, best};   // a wave past the end of the live list
-    // The table is walked in blocks of kMaskRounds * 64 = 1024 triangles.  MULTI = false is the
-    // build for scenes of at most one block (the host dispatches on num_tri): the loop below
-    // costs it nothing, while the general build needs 9 more VGPRs (7 waves per SIMD instead of
-    // 8).  The packet description is rebuilt per block (~100 instructions against the ~2000 of
-    // a block's culling) rather than kept alive across the candidate walk.
-    for (uint32_t blk0 = 0; blk0 < (MULTI ? num_tri : 1u); blk0 += kMaskRounds * 64u) {
-        const uint32_t blk1 = MULTI ? min(num_tri, blk0 + kMaskRounds * 64u) : num_tri;
+    // ITEMS are what the rounds walk: the rows 0 .. num_tri-1 of the table, or -- for a shadow packet
+    // narrow enough for the RX's direction table -- the entries of its cell's list (row = list[item]).
+    uint32_t n_items = num_tri;
+    const uint16_t *list = nullptr;
+    Packet P0 = packet_bounds(B, d, valid, shadow, apex);
+    HRT_STAT(kind, 0, 1);
+    HRT_STAT(kind, 1, P0.usable ? 1 : 0);
+    if (shadow && X.enabled && P0.usable) {
+        const F3 dc = sub3(B.c, {X.cx, X.cy, X.cz});
+        const bool inside = fast_sqrt(fdot3(dc, dc)) * 1.0001f + B.r <= X.region_r;
+        if (inside && P0.sina <= HRT_RXT_SIN_AQ && P0.ro <= X.ro_bin[rxk]) {
+            const uint32_t cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)rxt_cell(P0.ax));
+            const uint32_t e0 = X.off[rxk * HRT_RXT_BINS + cell], e1 = X.off[rxk * HRT_RXT_BINS + cell + 1u];
+            list = X.idx + e0;
+            n_items = e1 - e0;
+            HRT_STAT(kind, 6, 1);
+            HRT_STAT(kind, 7, n_items);
+        }
+    }
+    // The items are walked in blocks of kMaskRounds * 64 = 1024.  MULTI = false is the build for
+    // scenes of at most one block (the host dispatches on num_tri): the loop below costs it nothing,
+    // while the general build needs more VGPRs.  In the general build the packet description is
+    // rebuilt per block (~100 instructions against the ~2000 of a block's culling) rather than kept
+    // alive across the candidate walk.
+    for (uint32_t blk0 = 0; blk0 < (MULTI ? n_items : 1u); blk0 += kMaskRounds * 64u) {
+        const uint32_t blk1 = MULTI ? min(n_items, blk0 + kMaskRounds * 64u) : n_items;
         {
-            const Packet P = packet_bounds(B, d, valid, shadow, apex);
-            if (blk0 == 0) {
-                HRT_STAT(kind, 0, 1);
-                HRT_STAT(kind, 1, P.usable ? 1 : 0);
-            }
+            const Packet P = (MULTI && blk0 != 0u) ? packet_bounds(B, d, valid, shadow, apex) : P0;
             if (!P.usable) {
                 HRT_STAT(kind, 2, blk1 - blk0);
                 for (uint32_t j = blk0; j < blk1; ++j) HRT_STAGED_BODY(j)
                 continue;
             }
-#ifdef HRT_KERNEL_STATS
-            uint32_t ctot = 0;
-#endif
             for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
                 const uint32_t jl = base + lane;
                 bool cand = false;
-                if (jl < blk1)
-                    cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1],
-                                         tri[HRT_ROW * jl + 2], tri[HRT_ROW * jl + 3],
-                                         tri[HRT_ROW * jl + 4]);
+                if (jl < blk1) {
+                    const uint32_t row = list ? (uint32_t)list[jl] : jl;
+                    cand = !packet_culls(P, tri[HRT_ROW * row], tri[HRT_ROW * row + 1],
+                                         tri[HRT_ROW * row + 2], tri[HRT_ROW * row + 3],
+                                         tri[HRT_ROW * row + 4]);
+                }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
                 HRT_STAT(kind, 2, __popcll(m));
-#ifdef HRT_KERNEL_STATS
-                ctot += (uint32_t)__popcll(m);
-#endif
                 if (lane == 0) wmask[r] = m;
             }
-#ifdef HRT_KERNEL_STATS
-            HRT_STAT(kind, 6, ctot > 24u ? 1 : 0);
-            HRT_STAT(kind, 7, ctot > 24u ? ctot : 0);
-#endif
         }
         for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
             // written by this wave's lane 0 above, read back by all its lanes: same wave, in order
@@ -653,9 +679,10 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__
             const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
             const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
             m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
-            while (m) {   // ascending triangle index: the reference's tie-break order
-                const uint32_t j = base + (uint32_t)__builtin_ctzll(m);
+            while (m) {   // any order: ties go by (distance, original index)
+                const uint32_t it = base + (uint32_t)__builtin_ctzll(m);
                 m &= m - 1ull;
+                const uint32_t j = list ? (uint32_t)list[it] : it;   // `it` is wave-uniform: a scalar load
                 HRT_STAGED_BODY(j)
             }
         }
@@ -1049,6 +1076,7 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
 // (one block / many), 4 / 5 packet culling behind the leaf spheres + guard (one block / many).
 template <int VARIANT, typename TriPtr, typename TgPtr, typename LeafPtr>
 __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, const hrt_kaccel &A,
+                                           const hrt_krxt &X, uint32_t rxk,
                                            const uint32_t *__restrict__ orig, uint32_t num_tri, F3 o,
                                            F3 d, bool valid, uint32_t lane, const Ball &B,
                                            const bool shadow, F3 apex, unsigned long long *wmask,
@@ -1063,8 +1091,8 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, c
         if (valid) h = closest_hit_staged(tri, orig, num_tri, o, d);
         return h;
     } else if constexpr (VARIANT == 2 || VARIANT == 3) {
-        return closest_hit_packet<(VARIANT == 3)>(tri, orig, num_tri, o, d, valid, lane, B, shadow, apex,
-                                                  wmask, kind);
+        return closest_hit_packet<(VARIANT == 3)>(tri, orig, X, rxk, num_tri, o, d, valid, lane, B, shadow,
+                                                  apex, wmask, kind);
     } else if constexpr (VARIANT == 6) {
         return closest_hit_big(tri, leaf, A, num_tri, o, d, valid, lane, shadow, apex, wmask,
                                reinterpret_cast<uint32_t *>(wleaf), kind);
@@ -1385,7 +1413,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
 #ifdef HRT_KERNEL_STATS
         const long long t_unit0 = clock64();
 #endif
-        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.acc.orig, T, o, d, valid, lane, ball, shadow,
+        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, k, P.acc.orig, T, o, d, valid, lane, ball, shadow,
                                            apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
 #ifdef HRT_KERNEL_STATS
         if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks
@@ -1826,6 +1854,41 @@ __global__ __launch_bounds__(1024) void hrt_launch_order_kernel(const uint32_t *
     (void)num_paths;
 }
 
+// Builder of the per-RX direction tables (hrt_krxt): one wave per (rx, cell); the lanes take the
+// triangles 64 at a time through packet_culls with the CELL as the packet -- lines through the ball
+// (rx, ro_bin) with directions within the cell's cone (widened by the largest packet half-angle
+// served), origins anywhere in the scene's ball (so the tolerances are the largest any packet can
+// have, and the "behind the origin" part of the test can never fire).  Whatever is not culled here
+// cannot be culled for any packet inside the cell.  Output: candidate bit masks [rx][cell][T / 64].
+__global__ __launch_bounds__(64) void hrt_rxt_build_kernel(const float *tri_f, uint32_t num_tri,
+                                                           const float *rx_pos, const float *bin_dir4,
+                                                           const float *bin_cs2, const float *ro_bin,
+                                                           float cx, float cy, float cz, float region_r,
+                                                           unsigned long long *masks)
+{
+    const float4 *tri = reinterpret_cast<const float4 *>(tri_f);
+    const uint32_t cell = blockIdx.x, rx = blockIdx.y, lane = threadIdx.x;
+    const uint32_t W = (num_tri + 63u) / 64u;
+    Packet P;
+    P.oc = {rx_pos[3 * rx], rx_pos[3 * rx + 1], rx_pos[3 * rx + 2]};
+    P.ro = ro_bin[rx];
+    P.bc = {cx, cy, cz};
+    P.br = region_r;
+    P.ax = {bin_dir4[4 * cell], bin_dir4[4 * cell + 1], bin_dir4[4 * cell + 2]};
+    P.cosa = bin_cs2[2 * cell];
+    P.sina = bin_cs2[2 * cell + 1];
+    P.usable = true;
+    for (uint32_t r = 0; r < W; ++r) {
+        const uint32_t j = r * 64u + lane;
+        bool cand = false;
+        if (j < num_tri)
+            cand = !packet_culls(P, tri[HRT_ROW * j], tri[HRT_ROW * j + 1], tri[HRT_ROW * j + 2],
+                                 tri[HRT_ROW * j + 3], tri[HRT_ROW * j + 4]);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        if (lane == 0) masks[((uint64_t)rx * HRT_RXT_BINS + cell) * W + r] = m;
+    }
+}
+
 // launch Doppler term of the scatter records, src/compute_paths.c:494-500: out[p] =
 // dot(tx_vel, d_p) * f/c in the reference's float sequence (no contraction in this file)
 __global__ void hrt_fs0_kernel(const float *dirs, uint64_t n, float vx, float vy, float vz, float mult,
@@ -2023,6 +2086,15 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
     hipLaunchKernelGGL(hrt_launch_dirs_kernel, dim3((uint32_t)((num_local + 255) / 256)), dim3(256),
                        0, (hipStream_t)stream, num_paths, rank, count, chunk, num_local, d_dirs,
                        d_fix_count, d_fix_list, fix_cap);
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_pos, uint32_t num_rx,
+                      const float *d_bin_dir4, const float *d_bin_cs2, const float *d_ro_bin,
+                      float cx, float cy, float cz, float region_r, unsigned long long *d_masks, void *stream)
+{
+    hipLaunchKernelGGL(hrt_rxt_build_kernel, dim3(HRT_RXT_BINS, num_rx), dim3(64), 0, (hipStream_t)stream,
+                       d_tri, num_tri, d_rx_pos, d_bin_dir4, d_bin_cs2, d_ro_bin, cx, cy, cz, region_r, d_masks);
     return (int)hipGetLastError();
 }
 

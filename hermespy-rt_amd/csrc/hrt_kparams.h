@@ -59,6 +59,25 @@ typedef struct {
     const float *pl_rec;
 } hrt_kaccel;
 
+/* ---- per-RX direction tables for the shadow rays (host: problem.c; kernels: closest_hit_packet) ----
+ * All shadow rays of a trace kind converge on one RX, so which triangles can possibly be met is a
+ * function of the DIRECTION seen from that RX: the directions are binned on a cube map (6 faces x
+ * n x n cells), and per (RX, cell) the list of triangles that packet culling cannot reject for the
+ * whole cell (widened by the largest packet half-angle served, HRT_RXT_SIN_AQ) is computed once
+ * per problem, on the device, with the very same test.  A shadow packet then culls only its cell's
+ * list -- typically one round instead of T / 64. */
+#define HRT_RXT_N 48                /* cells per cube-face edge */
+#define HRT_RXT_BINS (6 * HRT_RXT_N * HRT_RXT_N)
+#define HRT_RXT_SIN_AQ 0.05233596f  /* sin(3 deg): packets wider than this use the whole table */
+#define HRT_RXT_MAX_TRI 4096u       /* tables are built for scenes up to this many triangles */
+typedef struct {
+    uint32_t enabled;
+    float cx, cy, cz, region_r;     /* the ball every ray origin of the scene lies in */
+    const float *ro_bin;            /* [num_rx] line-point radius the lists were built for */
+    const uint32_t *off;            /* [num_rx * HRT_RXT_BINS + 1] */
+    const uint16_t *idx;            /* table rows */
+} hrt_krxt;
+
 typedef struct {
     /* scene (device pointers) */
     const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
@@ -66,6 +85,7 @@ typedef struct {
     const float *mat;     /* [17][HRT_MAT_FLOATS] */
     uint32_t num_tri, num_mesh;
     hrt_kaccel acc;
+    hrt_krxt rxt;
     /* endpoints (device pointers, [n][3]) */
     const float *rx_pos, *tx_pos, *rx_vel, *tx_vel;
     uint32_t num_rx, num_tx;
@@ -108,6 +128,9 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream);
+int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_pos, uint32_t num_rx,
+                      const float *d_bin_dir4, const float *d_bin_cs2, const float *d_ro_bin,
+                      float cx, float cy, float cz, float region_r, unsigned long long *d_masks, void *stream);
 int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream);
 int hrt_hip_launch_order(const uint32_t *d_seg_start, const uint32_t *d_seg_band, uint32_t num_seg,
                          uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
