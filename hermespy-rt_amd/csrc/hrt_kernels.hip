@@ -1308,8 +1308,11 @@ __device__ __forceinline__ F3 shadow_dir(F3 o, F3 rx, float &d2rx)
 #ifndef HRT_TRACE_WAVES_PER_SIMD
 #define HRT_TRACE_WAVES_PER_SIMD 1
 #endif
+#ifndef HRT_TRACE_WAVES_V2
+#define HRT_TRACE_WAVES_V2 7   /* the small-table packet kernel: at most 72 VGPRs (measured C3: 1.704 ms at 7, 1.706 at 8 with 28 B of scratch, 1.743 at 6, 1.757 unconstrained) */
+#endif
 template <bool TRI_IN_LDS, int VARIANT>
-__global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace_kernel(
+__global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT_TRACE_WAVES_PER_SIMD)) void hrt_trace_kernel(
     const hrt_kparams P, const uint32_t b)
 {
     extern __shared__ float4 lds[];
@@ -1322,7 +1325,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
     const uint32_t k_lo = first ? P.num_rx : 0u;
     const uint32_t k_hi = (b < P.num_bounces) ? P.num_rx + 1u : P.num_rx;
     const uint32_t kinds = k_hi - k_lo;
-    const uint32_t n_units = n_chunks * kinds;   // < 2^32: at most 2^24 chunks x 33 kinds
+    // (static deal: chunks padded to a multiple of 8, see the XCD-aware numbering below)
+    const uint32_t n_units = (VARIANT == 6 ? n_chunks : ((n_chunks + 7u) & ~7u)) * kinds;   // < 2^32
     if (blockIdx.x >= n_units) return;
 
     const uint32_t T = P.num_tri;
@@ -1347,8 +1351,10 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
                                    (HRT_BLOCK / 64u) * kMaskRounds) + (HRT_BLOCK / 64u) * kMaskRounds);
     if (TRI_IN_LDS) {
         for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
-        for (uint32_t k = tid; k < T; k += HRT_BLOCK) l_tg[k] = g_tg[k];
-        for (uint32_t k = tid; k < 2u * n_leaf; k += HRT_BLOCK) l_leaf[k] = g_leaf[k];
+        if constexpr (VARIANT >= 4) {   // guard pairs and leaf records: only the tree variants read them
+            for (uint32_t k = tid; k < T; k += HRT_BLOCK) l_tg[k] = g_tg[k];
+            for (uint32_t k = tid; k < 2u * n_leaf; k += HRT_BLOCK) l_leaf[k] = g_leaf[k];
+        }
     }
     for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
         l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
@@ -1380,8 +1386,21 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_TRACE_WAVES_PER_SIMD) void hrt_trace
             __syncthreads();
         }
         if (unit >= n_units) break;
-        const uint32_t chunk = unit / kinds;
-        const uint32_t k = k_lo + (unit - chunk * kinds);
+        // XCD-aware numbering (static deal): workgroups b and b + 8 share an XCD and its L2, so the
+        // `kinds` traces of one chunk -- which re-read the same origins -- go to workgroups 8 apart
+        // instead of to `kinds` neighbouring workgroups on different XCDs.  With q = unit / 8 and
+        // x = unit % 8: chunk = (q / kinds) * 8 + x, kind = q % kinds (a bijection on the padded range;
+        // chunks past the end are skipped).
+        uint32_t chunk, k;
+        if constexpr (VARIANT == 6) {
+            chunk = unit / kinds;
+            k = k_lo + (unit - chunk * kinds);
+        } else {
+            const uint32_t q = unit >> 3, x = unit & 7u;
+            chunk = (q / kinds) * 8u + x;
+            k = k_lo + q % kinds;
+            if (chunk >= n_chunks) continue;   // padding of the last group of 8 chunks
+        }
         const uint32_t i = chunk * HRT_BLOCK + tid;
         const uint32_t i4 = i * 4u;
         const bool valid = i < n_in;
