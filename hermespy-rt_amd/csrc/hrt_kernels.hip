@@ -1442,8 +1442,16 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
         }
 #endif
         if (valid) {
-            stu(res_blk(P, k), 0u, i4, h.tri);
-            stf(res_blk(P, k), cap4, i4, h.t);
+            // a shadow trace is consumed as "which triangle (for the incidence angle), and is it
+            // within 1 m (the reference's blocking test, quirk Q6)": one word, bit 31 = blocked,
+            // 0x7fffffff = nothing hit; the bounce itself needs triangle and distance
+            if (shadow) {
+                const uint32_t code = (h.tri == HRT_NO_HIT) ? 0x7fffffffu : (h.tri | ((h.t <= 1.f) ? 0x80000000u : 0u));
+                stu(res_blk(P, k), 0u, i4, code);
+            } else {
+                stu(res_blk(P, k), 0u, i4, h.tri);
+                stf(res_blk(P, k), cap4, i4, h.t);
+            }
         }
         // the bounce itself: how many rays of this chunk survive.  With the counts of all chunks
         // known BEFORE the shade kernel runs, that kernel can write every survivor straight to
@@ -1562,15 +1570,17 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                     const float4 rp = l_rx[rx];
                     float d2rx;
                     const F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
-                    uint32_t stri = ldu(res_blk(P, rx), 0u, i4);
-                    const float st = ldf(res_blk(P, rx), cap4, i4);
+                    const uint32_t code = ldu(res_blk(P, rx), 0u, i4);   // see the trace kernel
+                    uint32_t stri = code & 0x7fffffffu;
+                    const bool near1 = (code >> 31) != 0u;
+                    if (stri == 0x7fffffffu) stri = HRT_NO_HIT;
                     if (stri != HRT_NO_HIT && stri >= P.num_tri) {   // cannot happen; never fault
                         atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
                         stri = HRT_NO_HIT;
                     }
                     if (stri != HRT_NO_HIT)
                         theta = incidence_angle(gather3(tri_r, HRT_TRI_FLOATS * 4u, stri, 36u), w);
-                    if (stri != HRT_NO_HIT && st <= 1.f) {
+                    if (stri != HRT_NO_HIT && near1) {
                         stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, 0.f);
                         stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, 0.f);
                         stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, 0.f);
