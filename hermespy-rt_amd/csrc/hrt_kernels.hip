@@ -40,6 +40,9 @@
 //     ~2^-29 per evaluation).
 //   * No MFMA: this is branchy intersection, not a contraction.
 #include <hip/hip_runtime.h>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>   // radix sort of the re-sort keys (a library primitive; the
+                                // key and permutation kernels around it are below)
 
 #include <stdint.h>
 #include <stdio.h>
@@ -1228,6 +1231,10 @@ __device__ __forceinline__ Rsrc hit_blk(const hrt_kparams &P, uint32_t b)
 {
     return make_rsrc(P.ws + P.off_hits + (uint64_t)b * P.hit_block_bytes);
 }
+__device__ __forceinline__ Rsrc hit_out(const hrt_kparams &P, uint32_t b)
+{
+    return P.sort.enabled ? make_rsrc(P.ws + P.sort.off_scratch) : hit_blk(P, b);
+}
 __device__ __forceinline__ Rsrc rec_blk(const hrt_kparams &P, uint32_t b, uint32_t rx)
 {
     return make_rsrc(P.ws + P.off_recs + (uint64_t)b * P.rec_block_bytes + (uint64_t)rx * 9u * P.cap * 4u);
@@ -1687,21 +1694,22 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             }
             if (hit) {
                 const uint32_t k4 = (chunk_off + before + lane_prefix(m)) * 4u;
-                stf(hit_blk(P, b), H_RAY * cap4, k4, __uint_as_float(ray));
-                stf(hit_blk(P, b), H_TRI * cap4, k4, __uint_as_float(ntri));
-                stf(hit_blk(P, b), H_THETA * cap4, k4, nth);
-                stf(hit_blk(P, b), H_FS0 * cap4, k4, fs0);
-                stf(hit_blk(P, b), H_OX * cap4, k4, o.x);
-                stf(hit_blk(P, b), H_OY * cap4, k4, o.y);
-                stf(hit_blk(P, b), H_OZ * cap4, k4, o.z);
-                stf(hit_blk(P, b), H_DX * cap4, k4, d.x);
-                stf(hit_blk(P, b), H_DY * cap4, k4, d.y);
-                stf(hit_blk(P, b), H_DZ * cap4, k4, d.z);
-                stf(hit_blk(P, b), H_A0 * cap4, k4, a0);
-                stf(hit_blk(P, b), H_A1 * cap4, k4, a1);
-                stf(hit_blk(P, b), H_A2 * cap4, k4, a2);
-                stf(hit_blk(P, b), H_A3 * cap4, k4, a3);
-                stf(hit_blk(P, b), H_TAU * cap4, k4, tau);
+                // (the block the survivors go to: hit block b, or the scratch the re-sort reads from)
+                stf(hit_out(P, b), H_RAY * cap4, k4, __uint_as_float(ray));
+                stf(hit_out(P, b), H_TRI * cap4, k4, __uint_as_float(ntri));
+                stf(hit_out(P, b), H_THETA * cap4, k4, nth);
+                stf(hit_out(P, b), H_FS0 * cap4, k4, fs0);
+                stf(hit_out(P, b), H_OX * cap4, k4, o.x);
+                stf(hit_out(P, b), H_OY * cap4, k4, o.y);
+                stf(hit_out(P, b), H_OZ * cap4, k4, o.z);
+                stf(hit_out(P, b), H_DX * cap4, k4, d.x);
+                stf(hit_out(P, b), H_DY * cap4, k4, d.y);
+                stf(hit_out(P, b), H_DZ * cap4, k4, d.z);
+                stf(hit_out(P, b), H_A0 * cap4, k4, a0);
+                stf(hit_out(P, b), H_A1 * cap4, k4, a1);
+                stf(hit_out(P, b), H_A2 * cap4, k4, a2);
+                stf(hit_out(P, b), H_A3 * cap4, k4, a3);
+                stf(hit_out(P, b), H_TAU * cap4, k4, tau);
             }
         }
     }
@@ -1918,6 +1926,90 @@ __global__ __launch_bounds__(64) void hrt_rxt_build_kernel(const float *tri_f, u
     }
 }
 
+// ===================================================================================
+// Re-sort of the survivors of bounce b (hrt_ksort): keys, then (rocPRIM, in the shim) a stable
+// radix sort of (key, index), then the permutation of the 15 field arrays from the scratch block
+// into hit block b.  The number of survivors is only known on the device (counts[b + 1]); entries
+// beyond it get the largest key and are not moved.
+// ===================================================================================
+__device__ __forceinline__ uint32_t spread5(uint32_t v)   // 5 bits -> every third bit
+{
+    v &= 31u;
+    v = (v | (v << 8)) & 0x100fu;
+    v = (v | (v << 4)) & 0x10c3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+
+__global__ void hrt_sort_keys_kernel(const hrt_kparams P, const uint32_t b)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.cap) return;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    const uint32_t n = counts[b + 1];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(P.ws + P.sort.off_keys);
+    uint32_t *idx = keys + 2u * P.cap;
+    uint32_t key = 0xffffffffu;
+    if (i < n) {
+        const uint32_t cap4 = (uint32_t)P.cap * 4u, i4 = i * 4u;
+        const Rsrc r = make_rsrc(P.ws + P.sort.off_scratch);
+        const uint32_t ray = ldu(r, H_RAY * cap4, i4);
+        const F3 o = {ldf(r, H_OX * cap4, i4), ldf(r, H_OY * cap4, i4), ldf(r, H_OZ * cap4, i4)};
+        const F3 d = {ldf(r, H_DX * cap4, i4), ldf(r, H_DY * cap4, i4), ldf(r, H_DZ * cap4, i4)};
+        const uint32_t tx = ray / P.num_local;
+        // cell of the origin: bits[k] bits per axis (cells of about equal edge: the host gives the
+        // longer axes more bits), concatenated x | y | z, split into a coarse part (the top `hi` bits
+        // of every axis) and a fine part
+        auto cell = [](float x, float lo, float inv, uint32_t bits) {
+            const float u = (x - lo) * inv, top = (float)((1u << bits) - 1u);
+            return (uint32_t)(u > 0.f ? (u < top ? (int)u : (int)top) : 0);   // NaN -> 0
+        };
+        const uint32_t bx = P.sort.bits[0], by = P.sort.bits[1], bz = P.sort.bits[2];
+        const uint32_t cx = cell(o.x, P.sort.lo[0], P.sort.inv_cell[0], bx);
+        const uint32_t cy = cell(o.y, P.sort.lo[1], P.sort.inv_cell[1], by);
+        const uint32_t cz = cell(o.z, P.sort.lo[2], P.sort.inv_cell[2], bz);
+        // interleave the axes' bits from the least significant up (an axis that runs out of bits
+        // drops out): a Morton code for cells of unequal counts; its low `nfine` bits sort BEHIND
+        // the direction bin
+        uint32_t code = 0u, pos = 0u;
+#pragma unroll
+        for (uint32_t lv = 0; lv < 15u; ++lv) {
+            if (lv < bx) code |= ((cx >> lv) & 1u) << pos++;
+            if (lv < by) code |= ((cy >> lv) & 1u) << pos++;
+            if (lv < bz) code |= ((cz >> lv) & 1u) << pos++;
+        }
+        const uint32_t fbits = P.sort.nfine;
+        const uint32_t coarse = code >> fbits, fine = code & ((1u << fbits) - 1u);
+        // direction bin: cube face (3 bits) x a dir_res x dir_res grid of the two minor components
+        const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+        uint32_t f = 0u;
+        float mj = d.x, c1 = d.y, c2 = d.z;
+        if (ay > ax && ay >= az) { f = 1u; mj = d.y; c1 = d.z; c2 = d.x; }
+        else if (az > ax && az > ay) { f = 2u; mj = d.z; c1 = d.x; c2 = d.y; }
+        const float inv = 1.f / mj, res = (float)P.sort.dir_res;
+        auto q = [&](float c) {
+            const float u = (c * inv * 0.5f + 0.5f) * res;
+            return (uint32_t)(u > 0.f ? (u < res - 1.f ? (int)u : (int)res - 1) : 0);   // NaN -> 0
+        };
+        const uint32_t db = (((f + (mj < 0.f ? 3u : 0u)) * P.sort.dir_res + q(c1)) * P.sort.dir_res) + q(c2);
+        key = (tx << P.sort.tx_shift) | (((coarse << P.sort.dir_bits) | db) << fbits) | fine;
+    }
+    keys[i] = key;
+    idx[i] = i;
+}
+
+__global__ void hrt_sort_permute_kernel(const hrt_kparams P, const uint32_t b)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    if (i >= counts[b + 1]) return;
+    const uint32_t *perm = reinterpret_cast<const uint32_t *>(P.ws + P.sort.off_keys) + 3u * P.cap;   // sorted index
+    const uint32_t src4 = perm[i] * 4u, dst4 = i * 4u, cap4 = (uint32_t)P.cap * 4u;
+    const Rsrc in = make_rsrc(P.ws + P.sort.off_scratch), out = hit_blk(P, b);
+#pragma unroll
+    for (uint32_t f = 0; f < 15u; ++f) stu(out, f * cap4, dst4, ldu(in, f * cap4, src4));
+}
+
 // launch Doppler term of the scatter records, src/compute_paths.c:494-500: out[p] =
 // dot(tx_vel, d_p) * f/c in the reference's float sequence (no contraction in this file)
 __global__ void hrt_fs0_kernel(const float *dirs, uint64_t n, float vx, float vy, float vz, float mult,
@@ -2115,6 +2207,28 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
     hipLaunchKernelGGL(hrt_launch_dirs_kernel, dim3((uint32_t)((num_local + 255) / 256)), dim3(256),
                        0, (hipStream_t)stream, num_paths, rank, count, chunk, num_local, d_dirs,
                        d_fix_count, d_fix_list, fix_cap);
+    return (int)hipGetLastError();
+}
+
+uint64_t hrt_hip_sort_temp_bytes(uint64_t cap)
+{
+    size_t bytes = 0;
+    uint32_t *null = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, null, null, null, null, (size_t)cap, 0u, 32u, (hipStream_t) nullptr);
+    return (uint64_t)bytes;
+}
+
+int hrt_hip_sort_hits(const hrt_kparams *P, uint32_t bounce, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t blocks = (uint32_t)((P->cap + 255) / 256);
+    hipLaunchKernelGGL(hrt_sort_keys_kernel, dim3(blocks), dim3(256), 0, st, *P, bounce);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(P->ws + P->sort.off_keys);
+    size_t tmp = (size_t)P->sort.tmp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(P->ws + P->sort.off_tmp, tmp, keys, keys + P->cap, keys + 2 * P->cap,
+                                             keys + 3 * P->cap, (size_t)P->cap, 0u, P->sort.key_bits, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(hrt_sort_permute_kernel, dim3(blocks), dim3(256), 0, st, *P, bounce);
     return (int)hipGetLastError();
 }
 

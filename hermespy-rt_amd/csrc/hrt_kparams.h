@@ -36,7 +36,7 @@ extern "C" {
 #define HRT_NODE_FLOATS 8           /* a sphere node: c.xyz, R, Lambda, -, -, -; a cone node: nu.xyz,
                                      * sin(beta+g), cos(beta+g); a guard record: p1.xyz, l, n.xyz, qs */
 #define HRT_ACCEL_MAX_LEVELS 3      /* 64-ary levels above the leaves: up to 64^4 = 16.7 M triangles */
-#define HRT_ACCEL_BIG 65536u        /* tables with more triangles get inner levels + the plane tree ... */
+#define HRT_ACCEL_BIG 131072u        /* tables with more triangles get inner levels + the plane tree ... */
 #define HRT_ACCEL_SPARSE 0.05       /* ... if the median leaf radius is below this fraction of the scene's */
 #define HRT_GUARD_SF 4.0            /* safety factor on the reference's noise bound 1e-5 l (S + l) */
 #define HRT_GUARD_MU 0.0625         /* big tables: a sphere is "far" when missed by mu * S and Lambda / 2 */
@@ -69,6 +69,7 @@ typedef struct {
 #define HRT_RXT_N 48                /* cells per cube-face edge */
 #define HRT_RXT_BINS (6 * HRT_RXT_N * HRT_RXT_N)
 #define HRT_RXT_SIN_AQ 0.05233596f  /* sin(3 deg): packets wider than this use the whole table */
+#define HRT_SORT_MIN_TRI 1024u      /* tables beyond this re-sort the live list between bounces by default */
 #define HRT_RXT_MAX_TRI 4096u       /* tables are built for scenes up to this many triangles */
 typedef struct {
     uint32_t enabled;
@@ -78,6 +79,25 @@ typedef struct {
     const uint16_t *idx;            /* table rows */
 } hrt_krxt;
 
+/* ---- re-sorting of the live list between bounces ----
+ * After a bounce the rays of a wave may have left different surfaces in different directions: the
+ * wave is then a wide packet and culls nothing.  With `enabled`, the shade kernel writes the
+ * survivors of bounce b into a scratch block, they are sorted by (TX, cell of the new origin, bin of
+ * the new direction) -- stable, so launch-order coherence survives inside a key -- and written in
+ * that order into hit block b, which every later consumer (next launch, record export) reads.
+ * Results do not depend on the order; only speed does. */
+typedef struct {
+    uint32_t enabled;
+    uint32_t key_bits;              /* bits of the key that are in use (sort passes) */
+    uint32_t tx_shift;              /* key = tx | coarse cell | direction bin | fine cell (most to least significant) */
+    uint32_t dir_res, dir_bits;     /* direction bins: 6 faces x dir_res^2, in dir_bits bits */
+    uint32_t bits[3], nfine;        /* cell bits per axis (15 in all, interleaved); how many of the code's low bits sort behind the direction */
+    float lo[3], inv_cell[3];       /* cell = (o - lo) * inv_cell */
+    uint64_t off_scratch;           /* workspace: a hit-block-sized scratch */
+    uint64_t off_keys;              /* workspace: 4 arrays of cap u32 (keys in/out, index in/out) */
+    uint64_t off_tmp, tmp_bytes;    /* workspace: rocPRIM temporary storage */
+} hrt_ksort;
+
 typedef struct {
     /* scene (device pointers) */
     const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
@@ -86,6 +106,7 @@ typedef struct {
     uint32_t num_tri, num_mesh;
     hrt_kaccel acc;
     hrt_krxt rxt;
+    hrt_ksort sort;
     /* endpoints (device pointers, [n][3]) */
     const float *rx_pos, *tx_pos, *rx_vel, *tx_vel;
     uint32_t num_rx, num_tx;
@@ -131,6 +152,8 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
 int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_pos, uint32_t num_rx,
                       const float *d_bin_dir4, const float *d_bin_cs2, const float *d_ro_bin,
                       float cx, float cy, float cz, float region_r, unsigned long long *d_masks, void *stream);
+uint64_t hrt_hip_sort_temp_bytes(uint64_t cap);
+int hrt_hip_sort_hits(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream);
 int hrt_hip_launch_order(const uint32_t *d_seg_start, const uint32_t *d_seg_band, uint32_t num_seg,
                          uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,

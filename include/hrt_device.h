@@ -155,6 +155,9 @@ typedef struct {
      * bounce itself) u32 triangle[cap] then f32 distance[cap] at off_res + (2k, 2k+1)*cap*4 */
     uint64_t off_res;
     uint64_t num_super;
+    /* re-sorting of the live list between bounces (only when the problem has it on, HRT_SORT_RAYS):
+     * a hit-block-sized scratch, 4 x cap u32 of keys / indices, the sort's temporary storage */
+    uint64_t off_sort_scratch, off_sort_keys, off_sort_tmp, sort_tmp_bytes;
 } hrt_layout;
 
 /* HRT_E_CAPACITY when num_tx * (local rays) exceeds 2^32 / (HRT_HIT_FIELDS * 4) - 512

@@ -9,7 +9,8 @@ against the oracle, every output array bit for bit:
     the reference's own order (HRT_NO_REORDER=1), the flat walk (2) -- on generated scenes,
     exact ties (duplicated triangles: the lexicographic (distance, original index) tie-break),
     endpoints exactly IN triangle planes, degenerate triangles;
-  * a generated city of 10^5 triangles (tests/scenes_gen.city) with the trees on by default.
+  * a generated city of 10^5 triangles (tests/scenes_gen.city): default, trees, plain flat walk;
+  * the re-sort of the live list between bounces (HRT_SORT_RAYS) on and off.
 The variant and the table order are latched per process / per problem: subprocesses."""
 import os
 import subprocess
@@ -46,8 +47,11 @@ print("ACCEL_OK", len(cases))
     dict(HRT_ACCEL_BIG="0", HRT_ACCEL_DEBUG="8"),  # ... with unusable packets cut down to single rays
     dict(HRT_ACCEL_BIG="0", HRT_NO_REORDER="1"),   # ... on the reference's own table order
     dict(HRT_TRACE_VARIANT="2"),                   # flat packet culling on the reordered table
+    dict(HRT_SORT_RAYS="1"),                       # live list re-sorted between bounces on every table
+    dict(HRT_SORT_RAYS="0"),                       # ... and never
+    dict(HRT_ACCEL_BIG="0", HRT_SORT_RAYS="1"),    # trees + re-sort
     dict(HRT_TRACE_VARIANT="0", HRT_NO_REORDER="1"),
-], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "plain_ref_order"])
+], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order"])
 def test_modes_are_bit_identical_to_the_oracle(env):
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
@@ -79,9 +83,12 @@ print("CITY_OK", live, "product %%.1f s, oracle %%.1f s" %% (t1 - t0, time.time(
 """
 
 
-@pytest.mark.parametrize("env", [dict(), dict(HRT_TRACE_VARIANT="2")], ids=["trees", "flat"])
+@pytest.mark.parametrize("env", [dict(), dict(HRT_ACCEL_BIG="65536"), dict(HRT_TRACE_VARIANT="2", HRT_SORT_RAYS="0")],
+                         ids=["default_flat_resorted", "trees_resorted", "flat"])
 def test_city_of_1e5_triangles(env):
-    """10^5 triangles: above HRT_ACCEL_BIG and sparse, so the trees are on by default."""
+    """10^5 triangles: by default the flat walk over a live list re-sorted between bounces (the trees
+    take over beyond HRT_ACCEL_BIG = 131 072 triangles on sparse scenes); with the threshold lowered
+    the sphere levels + plane tree; and the plain flat walk."""
     p = subprocess.run([sys.executable, "-c", CITY % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
     assert p.returncode == 0 and "CITY_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
