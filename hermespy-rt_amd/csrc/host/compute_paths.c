@@ -83,26 +83,6 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
     return (v && *v) ? strtoull(v, NULL, 10) : dflt;
 }
 
-typedef struct {
-    void *d_dirs, *d_ws, *d_order;
-    uint32_t *h_order;      /* coherent launch order of one batch */
-    float *h_dirs;          /* launch directions of the whole sphere, [np][3] */
-    uint32_t *h_counts;
-    float *h_los;
-    uint32_t *ray, *tri;    /* per-bounce downloads */
-    float *st[6];           /* o, d of the hits */
-    float *rec[HRT_REC_FIELDS];
-    uint64_t *mask;
-    float *rec2[HRT_REC_FIELDS];   /* second staging set: the copy of the next (bounce, rx) block */
-    uint64_t *mask2;              /* overlaps the dense scatter of the current one */
-    void *copy_stream, *copy_stream2;   /* two streams: two DMA engines (one engine moves ~28 GB/s) */
-    Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
-    uint8_t *active, *next_active;
-    float *dirs_batch;      /* gathered launch directions of one batch */
-    uint64_t *run_start;    /* per bounce: runs of equal TX in the hit list */
-    uint32_t *run_tx;
-    int device;
-} work_t;
 
 /* ---- launch-table cache -------------------------------------------------------------------
  * The launch directions depend on num_rays only, and the coherent launch order of an unbatched
@@ -170,7 +150,7 @@ static void work_free(work_t *w)
     if (w->d_ws) hrt_device_free(w->device, w->d_ws);
     free(w->h_dirs); free(w->h_counts); free(w->h_los);
     /* D2H staging is page-locked (hipHostMalloc): 2-4x the pageable copy rate */
-    hrt_hip_host_free(w->ray); hrt_hip_host_free(w->tri);
+    hrt_hip_host_free(w->ray); hrt_hip_host_free(w->tri); hrt_hip_host_free(w->fs0);
     for (int k = 0; k < 6; ++k) hrt_hip_host_free(w->st[k]);
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec[k]);
     hrt_hip_host_free(w->mask);
@@ -313,28 +293,6 @@ static void pool_release_all(void)
     pthread_mutex_unlock(&g_pool_lock);
 }
 
-/* everything one device worker needs */
-typedef struct {
-    /* the call (shared, read-only) */
-    Scene *scene;
-    const Vec3 *rx_pos, *tx_pos, *rx_vel, *tx_vel;
-    float f_ghz;
-    size_t nrx, ntx, np, nb, nq;
-    ChannelInfo *los, *scat;
-    RaysInfo *los_rays, *scat_rays;
-    uint32_t G;                 /* batches = round-robin shards of the launch set */
-    int host_launch, scatter_threads, use_pool;
-    /* this worker */
-    int index, count;           /* handles batches index, index + count, ... */
-    int device;
-    hrt_problem *prob;
-    work_t w;
-    uint64_t cap_alloc, ws_alloc, dirs_rows_alloc;
-    hrt_stats st;
-    double t_dev, t_rb, t_launch;
-    int rc;
-    char err[512];
-} dev_ctx;
 
 #define DL(dst, off, bytes)                                                              \
     do {                                                                                 \
@@ -342,8 +300,27 @@ typedef struct {
         if (rc) goto done;                                                               \
     } while (0)
 
+/* one call at a time owns the pool (compute_paths is not re-entrant; a concurrent call just
+ * allocates its own buffers) */
+int hrt_pool_begin(void)
+{
+    int taken = 0;
+    if (env_int("HRT_NO_CACHE", 0)) return 0;
+    pthread_mutex_lock(&g_pool_lock);
+    if (!g_pool_busy) { g_pool_busy = 1; taken = 1; }
+    pthread_mutex_unlock(&g_pool_lock);
+    return taken;
+}
+void hrt_pool_end(int taken)
+{
+    if (!taken) return;
+    pthread_mutex_lock(&g_pool_lock);
+    g_pool_busy = 0;
+    pthread_mutex_unlock(&g_pool_lock);
+}
+
 /* buffers of one worker, sized for its largest batch (from the pool when they fit) */
-static int worker_alloc(dev_ctx *c)
+int hrt_worker_alloc(dev_ctx *c)
 {
     work_t *w = &c->w;
     const size_t nb = c->nb, nrx = c->nrx, ntx = c->ntx, np = c->np;
@@ -386,6 +363,7 @@ static int worker_alloc(dev_ctx *c)
     int ok = w->h_order && w->h_counts && w->h_los && w->run_start && w->run_tx;
     ok &= hrt_hip_host_malloc((void **)&w->ray, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->tri, cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->fs0, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask, cap / 64 * 8 + 8) == 0;
     for (int k = 0; k < 6 && with_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w->st[k], cap * 4) == 0;
     for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w->rec[k], cap * 4) == 0;
@@ -399,7 +377,7 @@ static int worker_alloc(dev_ctx *c)
 }
 
 /* give the buffers back (pool) or free them */
-static void worker_release(dev_ctx *c)
+void hrt_worker_release(dev_ctx *c)
 {
     work_t *w = &c->w;
     free(w->h_dirs); w->h_dirs = NULL;
@@ -757,14 +735,10 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     for (int d = 0; d < D; ++d) { ctx[d].G = G; ctx[d].count = D; }
 
     /* ---- buffers (pooled between calls) ---- */
-    if (!env_int("HRT_NO_CACHE", 0)) {
-        pthread_mutex_lock(&g_pool_lock);
-        if (!g_pool_busy) { g_pool_busy = 1; pool_taken = 1; }
-        pthread_mutex_unlock(&g_pool_lock);
-    }
+    pool_taken = hrt_pool_begin();
     for (int d = 0; d < D && !rc; ++d) {
         ctx[d].use_pool = pool_taken;
-        rc = worker_alloc(&ctx[d]);
+        rc = hrt_worker_alloc(&ctx[d]);
     }
     if (rc) goto done;
 
@@ -880,14 +854,10 @@ done:
         if (ctx[d].rc == HRT_OK && rc) ctx[d].rc = rc;
     }
     for (int d = D - 1; d >= 0; --d) {
-        if (ctx[d].w.d_ws || ctx[d].w.ray) worker_release(&ctx[d]);
+        if (ctx[d].w.d_ws || ctx[d].w.ray) hrt_worker_release(&ctx[d]);
         hrt_problem_destroy(ctx[d].prob);
     }
-    if (pool_taken) {
-        pthread_mutex_lock(&g_pool_lock);
-        g_pool_busy = 0;
-        pthread_mutex_unlock(&g_pool_lock);
-    }
+    hrt_pool_end(pool_taken);
     free(ctx);
     st.t_total_s = hrt_now_s() - t_begin;
     if (!rc && stats) *stats = st;

@@ -84,6 +84,56 @@ int hrt_fail_hip(int hip_err, const char *what);
 
 double hrt_now_s(void);
 
+/* ---- buffers of one device worker of the drop-in calls (compute_paths.c), pooled between calls ---- */
+typedef struct {
+    void *d_dirs, *d_ws, *d_order;
+    uint32_t *h_order;      /* coherent launch order of one batch */
+    float *h_dirs;          /* launch directions of the whole sphere, [np][3] */
+    uint32_t *h_counts;
+    float *h_los;
+    uint32_t *ray, *tri;    /* per-bounce downloads */
+    float *fs0;             /* launch Doppler term of the hits (path-list writer) */
+    float *st[6];           /* o, d of the hits */
+    float *rec[HRT_REC_FIELDS];
+    uint64_t *mask;
+    float *rec2[HRT_REC_FIELDS];   /* second staging set: the copy of the next (bounce, rx) block */
+    uint64_t *mask2;              /* overlaps the dense scatter of the current one */
+    void *copy_stream, *copy_stream2;   /* two streams: two DMA engines (one engine moves ~28 GB/s) */
+    Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
+    uint8_t *active, *next_active;
+    float *dirs_batch;      /* gathered launch directions of one batch */
+    uint64_t *run_start;    /* per bounce: runs of equal TX in the hit list */
+    uint32_t *run_tx;
+    int device;
+} work_t;
+
+/* everything one device worker needs */
+typedef struct {
+    /* the call (shared, read-only) */
+    Scene *scene;
+    const Vec3 *rx_pos, *tx_pos, *rx_vel, *tx_vel;
+    float f_ghz;
+    size_t nrx, ntx, np, nb, nq;
+    ChannelInfo *los, *scat;
+    RaysInfo *los_rays, *scat_rays;
+    uint32_t G;                 /* batches = round-robin shards of the launch set */
+    int host_launch, scatter_threads, use_pool;
+    /* this worker */
+    int index, count;           /* handles batches index, index + count, ... */
+    int device;
+    hrt_problem *prob;
+    work_t w;
+    uint64_t cap_alloc, ws_alloc, dirs_rows_alloc;
+    hrt_stats st;
+    double t_dev, t_rb, t_launch;
+    int rc;
+    char err[512];
+} dev_ctx;
+int hrt_pool_begin(void);             /* 1 if this call owns the pool of kept buffers */
+void hrt_pool_end(int taken);
+int hrt_worker_alloc(dev_ctx *c);     /* needs c->prob, nrx, ntx, np, nb, G, index, device, use_pool, scat_rays */
+void hrt_worker_release(dev_ctx *c);  /* back to the pool (when c->rc == HRT_OK) or freed */
+
 /* host helpers shared by the dense writer and the path-list writer (compute_paths.c) */
 #define HRT_MAX_SCATTER_THREADS 32
 typedef void (*hrt_range_fn)(void *ctx, uint64_t i0, uint64_t i1, int tid);

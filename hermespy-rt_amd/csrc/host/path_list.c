@@ -142,13 +142,15 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     if (rc) return rc;
     st.t_setup_s = hrt_now_s() - t_begin;
 
+    dev_ctx wc;                      /* the drop-in's worker buffers: workspace + staging, pooled between calls */
+    memset(&wc, 0, sizeof wc);
+    int pool_taken = 0, have_buffers = 0;
     void *d_ws = NULL, *d_dirs = NULL, *d_order = NULL;
-    float *h_dirs = NULL, *h_field[HRT_REC_FIELDS] = {0}, *h_field2[HRT_REC_FIELDS] = {0}, *h_fs0 = NULL;
-    uint64_t *h_mask2 = NULL;
+    float *h_dirs = NULL, **h_field = NULL, **h_field2 = NULL, *h_fs0 = NULL;
+    uint64_t *h_mask = NULL, *h_mask2 = NULL;
     void *copy_stream = NULL;
     const int host_launch = (int)pl_env_u64("HRT_HOST_LAUNCH", 0);
     uint32_t *h_order = NULL, *h_ray = NULL, *h_tri = NULL, *h_counts = NULL;
-    uint64_t *h_mask = NULL;
     uint64_t cap_out = 0;
     const int threads = hrt_host_threads();
     double t_dev = 0.0, t_rb = 0.0, t_dirs = 0.0;
@@ -175,27 +177,23 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         G *= 2;
     }
     {
-        hrt_shard s0 = {np, 0, G, 0, (uint32_t)nb};
-        if ((rc = hrt_layout_query(prob, &s0, &L))) goto done;
-        const uint64_t n0 = hrt_shard_num_local(&s0), cap = L.cap;
-        if ((rc = hrt_device_malloc(device, &d_ws, L.total_bytes))) goto done;
-        if ((rc = hrt_device_malloc(device, &d_dirs, n0 * 12))) goto done;
-        if ((rc = hrt_device_malloc(device, &d_order, n0 * 4))) goto done;
-        h_dirs = (float *)malloc(n0 * 12);
-        h_order = (uint32_t *)malloc(n0 * 4);
-        h_counts = (uint32_t *)calloc(nb + 2, 4);
-        int ok = h_dirs && h_order && h_counts;
-        /* D2H staging is page-locked (hipHostMalloc): 2-4x the pageable copy rate */
-        ok &= hrt_hip_host_malloc((void **)&h_ray, cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&h_tri, cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&h_fs0, cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&h_mask, cap / 64 * 8 + 8) == 0;
-        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&h_field[k], cap * 4) == 0;
-        for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&h_field2[k], cap * 4) == 0;
-        ok &= hrt_hip_host_malloc((void **)&h_mask2, cap / 64 * 8 + 8) == 0;
-        ok &= hrt_hip_stream_create(&copy_stream) == 0;
+        wc.prob = prob; wc.nrx = nrx; wc.ntx = ntx; wc.np = np; wc.nb = nb; wc.G = G; wc.index = 0; wc.count = 1;
+        wc.device = device;
+        pool_taken = hrt_pool_begin();
+        wc.use_pool = pool_taken;
+        if ((rc = hrt_worker_alloc(&wc))) { wc.rc = rc; goto done; }
+        have_buffers = 1;
+        d_ws = wc.w.d_ws; d_dirs = wc.w.d_dirs; d_order = wc.w.d_order;
+        h_order = wc.w.h_order; h_counts = wc.w.h_counts;
+        h_ray = wc.w.ray; h_tri = wc.w.tri; h_fs0 = wc.w.fs0;
+        h_field = wc.w.rec; h_field2 = wc.w.rec2; h_mask = wc.w.mask; h_mask2 = wc.w.mask2;
+        copy_stream = wc.w.copy_stream;
+        if (host_launch) {
+            h_dirs = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
+            if (!h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+        }
         out->los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
-        if (!ok || !out->los) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+        if (!out->los) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
     }
     out->num_rx = (uint32_t)nrx;
     out->num_tx = (uint32_t)ntx;
@@ -317,14 +315,13 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     rc = HRT_OK;
 
 done:
-    if (d_ws) hrt_device_free(device, d_ws);
-    if (d_dirs) hrt_device_free(device, d_dirs);
-    if (d_order) hrt_device_free(device, d_order);
-    free(h_dirs); free(h_order); free(h_counts);
-    if (copy_stream) { hrt_hip_stream_sync(copy_stream); hrt_hip_stream_destroy(copy_stream); }
-    hrt_hip_host_free(h_ray); hrt_hip_host_free(h_tri); hrt_hip_host_free(h_fs0); hrt_hip_host_free(h_mask);
-    hrt_hip_host_free(h_mask2);
-    for (int k = 0; k < HRT_REC_FIELDS; ++k) { hrt_hip_host_free(h_field[k]); hrt_hip_host_free(h_field2[k]); }
+    if (have_buffers || wc.w.d_ws || wc.w.ray) {
+        wc.rc = rc;
+        if (copy_stream) hrt_hip_stream_sync(copy_stream);
+        hrt_worker_release(&wc);
+    }
+    hrt_pool_end(pool_taken);
+    free(h_dirs);
     hrt_problem_destroy(prob);
     if (rc != HRT_OK) hrt_path_list_free(out);
     return rc;
