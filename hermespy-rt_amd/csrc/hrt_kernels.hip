@@ -2144,9 +2144,7 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
-    // HRT_TRACE_VARIANT: unset = auto: the trees (inner sphere levels + plane tree) where the host
-    // built them -- big, sparse tables, csrc/host/accel.c -- and flat packet culling elsewhere
-    // (measured: on small and on dense tables the leaf spheres never pay: C3 1.81 vs 1.76 ms).
+    // HRT_TRACE_VARIANT: unset = auto (see below).
     // 6 = trees wherever built, else 4; 4 = packet culling behind the leaf spheres + guard; 2 = flat
     // packet culling; 1 = staged tests over all triangles; 0 = the reference's plain sequence.  All
     // give bit-identical results; the GPU tests run all of them.
@@ -2163,8 +2161,12 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
+    // auto (7): trees where the host built them; the leaf spheres + guard on tables of more than one
+    // block of 1024 triangles (where the live list is re-sorted between bounces, so that most leaves
+    // ARE far from a packet: city of 25 002 triangles 22.2 -> 17.9 ms, of 100 002 100 -> 87); the flat
+    // walk on small tables (C3: 1.67 vs 1.81 ms)
     const bool trees = P->acc.big && (variant >= 4);
-    const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees);
+    const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
     if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);

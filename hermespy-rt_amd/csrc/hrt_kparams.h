@@ -36,7 +36,7 @@ extern "C" {
 #define HRT_NODE_FLOATS 8           /* a sphere node: c.xyz, R, Lambda, -, -, -; a cone node: nu.xyz,
                                      * sin(beta+g), cos(beta+g); a guard record: p1.xyz, l, n.xyz, qs */
 #define HRT_ACCEL_MAX_LEVELS 3      /* 64-ary levels above the leaves: up to 64^4 = 16.7 M triangles */
-#define HRT_ACCEL_BIG 131072u        /* tables with more triangles get inner levels + the plane tree ... */
+#define HRT_ACCEL_BIG 524288u        /* tables with more triangles get inner levels + the plane tree ... */
 #define HRT_ACCEL_SPARSE 0.05       /* ... if the median leaf radius is below this fraction of the scene's */
 #define HRT_GUARD_SF 4.0            /* safety factor on the reference's noise bound 1e-5 l (S + l) */
 #define HRT_GUARD_MU 0.0625         /* big tables: a sphere is "far" when missed by mu * S and Lambda / 2 */

@@ -84,11 +84,11 @@ print("CITY_OK", live, "product %%.1f s, oracle %%.1f s" %% (t1 - t0, time.time(
 
 
 @pytest.mark.parametrize("env", [dict(), dict(HRT_ACCEL_BIG="65536"), dict(HRT_TRACE_VARIANT="2", HRT_SORT_RAYS="0")],
-                         ids=["default_flat_resorted", "trees_resorted", "flat"])
+                         ids=["default_leaves_resorted", "trees_resorted", "flat"])
 def test_city_of_1e5_triangles(env):
-    """10^5 triangles: by default the flat walk over a live list re-sorted between bounces (the trees
-    take over beyond HRT_ACCEL_BIG = 131 072 triangles on sparse scenes); with the threshold lowered
-    the sphere levels + plane tree; and the plain flat walk."""
+    """10^5 triangles: by default the leaf spheres + guard over a live list re-sorted between bounces
+    (the trees only take over beyond HRT_ACCEL_BIG = 524 288 triangles on sparse scenes); with the
+    threshold lowered the sphere levels + plane tree; and the plain flat walk."""
     p = subprocess.run([sys.executable, "-c", CITY % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
     assert p.returncode == 0 and "CITY_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
