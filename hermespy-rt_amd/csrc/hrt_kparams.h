@@ -70,7 +70,7 @@ typedef struct {
 #define HRT_RXT_BINS (6 * HRT_RXT_N * HRT_RXT_N)
 #define HRT_RXT_SIN_AQ 0.05233596f  /* sin(3 deg): packets wider than this use the whole table */
 #define HRT_SORT_MIN_TRI 1024u      /* tables beyond this re-sort the live list between bounces by default */
-#define HRT_RXT_MAX_TRI 4096u       /* tables are built for scenes up to this many triangles */
+#define HRT_RXT_MAX_TRI 1024u       /* tables are built for scenes up to this many triangles */
 typedef struct {
     uint32_t enabled;
     float cx, cy, cz, region_r;     /* the ball every ray origin of the scene lies in */
