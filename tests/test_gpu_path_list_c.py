@@ -47,3 +47,25 @@ def test_c_path_list_equals_dense_oracle(product_lib, name, npaths):
         clear = status == 2
         assert np.array_equal(los[..., 1][clear], ref["los"]["a_te_re"][clear])
         assert np.array_equal(los[..., 2][clear], ref["los"]["tau"][clear])
+
+
+def test_more_host_threads_than_the_writers_have_slots(product_lib, monkeypatch):
+    """HRT_HOST_THREADS above 32 used to index past the per-thread arrays of the list
+    writer once a hit block had more than 2.1 M entries (C3 at 3 M rays has 2.4 M at bounce 0).
+    The value is clamped now; the list and the dense form must come out the same as with 16."""
+    c = K.small(K.C3, 3000000)
+    monkeypatch.setenv("HRT_HOST_THREADS", "16")
+    st16 = lib.Stats()
+    a = abi.run_compute_paths_list(product_lib, *K.args(c), stats=st16)
+    monkeypatch.setenv("HRT_HOST_THREADS", "64")
+    st64 = lib.Stats()
+    b = abi.run_compute_paths_list(product_lib, *K.args(c), stats=st64)
+    assert int(st64.live[1]) > 2200000
+    assert a["rx"].size == b["rx"].size and int(st16.records) == int(st64.records)
+    for k in ("rx", "tx", "bounce", "path", "a_te_re", "tau", "mesh", "face"):
+        assert np.array_equal(a[k], b[k]), k
+    d64 = abi.run_compute_paths(product_lib, *K.args(K.small(K.C3, 600000)), with_rays=False)
+    monkeypatch.setenv("HRT_HOST_THREADS", "16")
+    d16 = abi.run_compute_paths(product_lib, *K.args(K.small(K.C3, 600000)), with_rays=False)
+    for k in ("a_te_re", "tau", "freq_shift"):
+        assert np.array_equal(d64["scat"][k].view(np.uint32), d16["scat"][k].view(np.uint32)), k
