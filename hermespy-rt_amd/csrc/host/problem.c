@@ -91,11 +91,14 @@ static void rxt_dir(uint32_t f, double u, double v, double out[3])
     out[0] = c[0] / l; out[1] = c[1] / l; out[2] = c[2] / l;
 }
 
-static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
+static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
 {
-    const uint32_t T = p->num_tri, nrx = p->num_rx;
-    const char *off_env = getenv("HRT_NO_RXT");
-    if (T == 0 || T > HRT_RXT_MAX_TRI || nrx > 64 || (off_env && *off_env && *off_env != '0')) return HRT_OK;
+    /* apexes: the RXs (shadow rays converge on them), then the TXs (the launch set leaves them) */
+    const uint32_t T = p->num_tri, n_rx = p->num_rx;
+    const char *off_env = getenv("HRT_NO_RXT"), *notx_env = getenv("HRT_NO_TXT");
+    if (T == 0 || T > HRT_RXT_MAX_TRI || n_rx > 64 || (off_env && *off_env && *off_env != '0')) return HRT_OK;
+    const uint32_t n_txt = (n_rx + p->num_tx <= 64 && !(notx_env && *notx_env && *notx_env != '0')) ? p->num_tx : 0u;
+    const uint32_t nrx = n_rx + n_txt;
     /* the ball every ray origin lies in: hit points are on triangles (+ 1e-4 along the new direction) */
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t j = 0; j < T; ++j) {
@@ -108,6 +111,14 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
                 if (x > hi[k]) hi[k] = x;
             }
     }
+    for (uint32_t t = 0; t < n_txt; ++t) {   /* ... and the launch set starts at the TXs */
+        const double x[3] = {tx_pos[t].x, tx_pos[t].y, tx_pos[t].z};
+        for (int k = 0; k < 3; ++k) {
+            if (!isfinite(x[k])) return HRT_OK;
+            if (x[k] < lo[k]) lo[k] = x[k];
+            if (x[k] > hi[k]) hi[k] = x[k];
+        }
+    }
     const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
     const double half = 0.5 * sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
     const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
@@ -118,12 +129,13 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
     float *bin_dir = (float *)malloc((size_t)NB * 4 * sizeof(float));
     float *bin_cs = (float *)malloc((size_t)NB * 2 * sizeof(float));
     float *ro_bin = (float *)malloc((size_t)nrx * sizeof(float));
+    float *apex = (float *)malloc((size_t)nrx * 3 * sizeof(float));
     uint64_t *masks = (uint64_t *)malloc((size_t)nrx * NB * W * 8);
     uint32_t *off = (uint32_t *)malloc(((size_t)nrx * NB + 1) * 4);
     int rc = HRT_OK, e;
     void *d_tmp = NULL;
     uint16_t *idx = NULL;
-    if (!bin_dir || !bin_cs || !ro_bin || !masks || !off) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
+    if (!bin_dir || !bin_cs || !ro_bin || !apex || !masks || !off) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
     const double aq = asin((double)HRT_RXT_SIN_AQ);
     for (uint32_t f = 0; f < 6; ++f)
         for (uint32_t iv = 0; iv < HRT_RXT_N; ++iv)
@@ -151,23 +163,30 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
                 bin_cs[2 * cell] = cs; bin_cs[2 * cell + 1] = sn;
             }
     for (uint32_t r = 0; r < nrx; ++r) {
-        const double dx = (double)rx_pos[r].x - c[0], dy = (double)rx_pos[r].y - c[1], dz = (double)rx_pos[r].z - c[2];
+        const Vec3 a = r < n_rx ? rx_pos[r] : tx_pos[r - n_rx];
+        apex[3 * r] = a.x; apex[3 * r + 1] = a.y; apex[3 * r + 2] = a.z;
+        const double dx = (double)a.x - c[0], dy = (double)a.y - c[1], dz = (double)a.z - c[2];
         const double lmax = (sqrt(dx * dx + dy * dy + dz * dz) + 2.0 * (double)region_r) * 1.001;
         ro_bin[r] = (float)(8.0 * 0.5 * 1.1920928955078125e-07 * lmax * 1.001 + 2e-7);
+        /* a launch packet: every origin IS the TX; the kernel takes the radius of its origin ball
+         * (1e-6 of the 1-norm of its centre, origin_ball()) plus the centre's distance from the TX */
+        if (r >= n_rx) ro_bin[r] = (float)(4e-6 * (fabs((double)a.x) + fabs((double)a.y) + fabs((double)a.z)) + 4e-6);
         if (!isfinite(ro_bin[r])) goto out;   /* an RX at infinity: no tables */
     }
     {
         const uint64_t b_dir = (uint64_t)NB * 16, b_cs = (uint64_t)NB * 8, b_ro = (uint64_t)nrx * 4 + 252;
-        const uint64_t b_mask = (uint64_t)nrx * NB * W * 8;
-        if ((e = hrt_hip_malloc(&d_tmp, b_dir + b_cs + (b_ro & ~255ull) + 256 + b_mask))) { rc = hrt_fail_hip(e, "hipMalloc(rxt build)"); goto out; }
+        const uint64_t b_mask = (uint64_t)nrx * NB * W * 8, b_apex = round_up((uint64_t)nrx * 12, 256);
+        if ((e = hrt_hip_malloc(&d_tmp, b_dir + b_cs + (b_ro & ~255ull) + 256 + b_apex + b_mask))) { rc = hrt_fail_hip(e, "hipMalloc(rxt build)"); goto out; }
         uint8_t *q = (uint8_t *)d_tmp;
         float *d_dir = (float *)q; q += b_dir;
         float *d_cs = (float *)q; q += b_cs;
         float *d_ro = (float *)q; q += (b_ro & ~255ull) + 256;
+        float *d_apex = (float *)q; q += b_apex;
         unsigned long long *d_masks = (unsigned long long *)q;
         if ((e = hrt_hip_h2d(d_dir, bin_dir, b_dir)) || (e = hrt_hip_h2d(d_cs, bin_cs, b_cs)) ||
-            (e = hrt_hip_h2d(d_ro, ro_bin, (uint64_t)nrx * 4))) { rc = hrt_fail_hip(e, "hipMemcpy(rxt build)"); goto out; }
-        if ((e = hrt_hip_rxt_build(p->d_tri, T, p->d_rx_pos, nrx, d_dir, d_cs, d_ro, cf[0], cf[1], cf[2], region_r,
+            (e = hrt_hip_h2d(d_ro, ro_bin, (uint64_t)nrx * 4)) ||
+            (e = hrt_hip_h2d(d_apex, apex, (uint64_t)nrx * 12))) { rc = hrt_fail_hip(e, "hipMemcpy(rxt build)"); goto out; }
+        if ((e = hrt_hip_rxt_build(p->d_tri, T, d_apex, nrx, d_dir, d_cs, d_ro, cf[0], cf[1], cf[2], region_r,
                                    d_masks, NULL))) { rc = hrt_fail_hip(e, "hrt_rxt_build_kernel"); goto out; }
         if ((e = hrt_hip_stream_sync(NULL))) { rc = hrt_fail_hip(e, "hipStreamSynchronize"); goto out; }
         if ((e = hrt_hip_d2h(masks, d_masks, b_mask))) { rc = hrt_fail_hip(e, "hipMemcpy D2H"); goto out; }
@@ -198,6 +217,7 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
         if ((e = hrt_hip_h2d(q, ro_bin, (uint64_t)nrx * 4)) || (e = hrt_hip_h2d(q + b_ro, off, ((uint64_t)nrx * NB + 1) * 4)) ||
             (total && (e = hrt_hip_h2d(q + b_ro + b_off, idx, total * 2)))) { rc = hrt_fail_hip(e, "hipMemcpy(rxt)"); goto out; }
         p->krxt.enabled = 1u;
+        p->krxt.num_txt = n_txt;
         p->krxt.cx = cf[0]; p->krxt.cy = cf[1]; p->krxt.cz = cf[2]; p->krxt.region_r = region_r;
         p->krxt.ro_bin = (const float *)q;
         p->krxt.off = (const uint32_t *)(q + b_ro);
@@ -206,7 +226,7 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos)
     }
 out:
     if (d_tmp) hrt_hip_free(d_tmp);
-    free(bin_dir); free(bin_cs); free(ro_bin); free(masks); free(off); free(idx);
+    free(bin_dir); free(bin_cs); free(ro_bin); free(apex); free(masks); free(off); free(idx);
     return rc;
 }
 
@@ -434,7 +454,7 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
         if (24u + txb > 32u) p->sort_rays = 0;   /* 15 bits of cell + up to 9 of direction + TX */
     }
     {
-        const int rcx = rxt_build(p, rx_pos);
+        const int rcx = rxt_build(p, rx_pos, tx_pos);
         if (rcx) { hrt_problem_destroy(p); return rcx; }
     }
     *out = p;

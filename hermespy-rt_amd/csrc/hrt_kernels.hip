@@ -621,8 +621,7 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__
                                                   uint32_t num_tri, F3 o, F3 d,
                                                   bool valid, uint32_t lane, const Ball &B,
                                                   const bool shadow, F3 apex,
-                                                  unsigned long long *wmask,
-                                                  [[maybe_unused]] int kind)
+                                                  unsigned long long *wmask, int kind)
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT, who_o = 0u;
@@ -635,10 +634,15 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__
     Packet P0 = packet_bounds(B, d, valid, shadow, apex);
     HRT_STAT(kind, 0, 1);
     HRT_STAT(kind, 1, P0.usable ? 1 : 0);
-    if (shadow && X.enabled && P0.usable) {
+    // (a launch packet -- kind 0, rxk = num_rx + tx, apex = the TX -- leaves its apex as a shadow packet
+    // arrives at its own: same tables; its lines pass within ro of the ball's centre, which is the TX
+    // itself unless the wave straddles two TXs)
+    if ((shadow || (kind == 0 && X.num_txt != 0u)) && X.enabled && P0.usable) {
         const F3 dc = sub3(B.c, {X.cx, X.cy, X.cz});
         const bool inside = fast_sqrt(fdot3(dc, dc)) * 1.0001f + B.r <= X.region_r;
-        if (inside && P0.sina <= HRT_RXT_SIN_AQ && P0.ro <= X.ro_bin[rxk]) {
+        float ro_apex = P0.ro;
+        if (!shadow) ro_apex += (fabsf(B.c.x - apex.x) + fabsf(B.c.y - apex.y)) + fabsf(B.c.z - apex.z);
+        if (inside && P0.sina <= HRT_RXT_SIN_AQ && ro_apex <= X.ro_bin[rxk]) {
             const uint32_t cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)rxt_cell(P0.ax));
             const uint32_t e0 = X.off[rxk * HRT_RXT_BINS + cell], e1 = X.off[rxk * HRT_RXT_BINS + cell + 1u];
             list = X.idx + e0;
@@ -1427,19 +1431,28 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
             }
         }
         F3 apex = {0.f, 0.f, 0.f};
+        uint32_t apex_k = k;   // which direction table serves this trace: the RX's, or (launch) the TX's
         if (shadow) {
             const float4 rp = l_rx[k];
             apex = {rp.x, rp.y, rp.z};
             float d2rx;
             const F3 w = shadow_dir(o, apex, d2rx);
             if (valid) d = w;
+        } else if (first && P.rxt.num_txt != 0u) {
+            uint32_t tx = 0u;
+            if (P.num_tx != 1u) {
+                tx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((chunk * HRT_BLOCK + (tid & ~63u)) / P.num_local));
+                tx = min(tx, P.num_tx - 1u);
+            }
+            apex = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
+            apex_k = P.num_rx + tx;
         }
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
         if constexpr (VARIANT >= 2 && VARIANT != 6) ball = origin_ball(o, valid);
 #ifdef HRT_KERNEL_STATS
         const long long t_unit0 = clock64();
 #endif
-        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, k, P.acc.orig, T, o, d, valid, lane, ball, shadow,
+        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane, ball, shadow,
                                            apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
 #ifdef HRT_KERNEL_STATS
         if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks

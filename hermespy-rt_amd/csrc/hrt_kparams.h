@@ -73,9 +73,11 @@ typedef struct {
 #define HRT_RXT_MAX_TRI 1024u       /* tables are built for scenes up to this many triangles */
 typedef struct {
     uint32_t enabled;
+    uint32_t num_txt;               /* tables of the TXs follow those of the RXs (the launch set leaves a TX
+                                     * as the shadow rays arrive at an RX): num_tx, or 0 = none */
     float cx, cy, cz, region_r;     /* the ball every ray origin of the scene lies in */
-    const float *ro_bin;            /* [num_rx] line-point radius the lists were built for */
-    const uint32_t *off;            /* [num_rx * HRT_RXT_BINS + 1] */
+    const float *ro_bin;            /* [num_rx + num_txt] line-point radius the lists were built for */
+    const uint32_t *off;            /* [(num_rx + num_txt) * HRT_RXT_BINS + 1] */
     const uint16_t *idx;            /* table rows */
 } hrt_krxt;
 

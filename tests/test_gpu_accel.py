@@ -51,7 +51,10 @@ print("ACCEL_OK", len(cases))
     dict(HRT_SORT_RAYS="0"),                       # ... and never
     dict(HRT_ACCEL_BIG="0", HRT_SORT_RAYS="1"),    # trees + re-sort
     dict(HRT_TRACE_VARIANT="0", HRT_NO_REORDER="1"),
-], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order"])
+    dict(HRT_NO_TXT="1"),                          # direction tables for the RXs only (default: RXs and TXs)
+    dict(HRT_NO_RXT="1"),                          # ... and none at all
+], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order",
+        "rx_tables_only", "no_tables"])
 def test_modes_are_bit_identical_to_the_oracle(env):
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
