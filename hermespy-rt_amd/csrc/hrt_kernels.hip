@@ -1319,6 +1319,9 @@ __device__ __forceinline__ F3 shadow_dir(F3 o, F3 rx, float &d2rx)
 #ifndef HRT_TRACE_WAVES_PER_SIMD
 #define HRT_TRACE_WAVES_PER_SIMD 1
 #endif
+#ifndef HRT_HALF_RESULTS_MAX
+#define HRT_HALF_RESULTS_MAX 0x7fffu   /* tables of fewer triangles: shadow results are half words (0 = never) */
+#endif
 #ifndef HRT_TRACE_WAVES_V2
 #define HRT_TRACE_WAVES_V2 7   /* the small-table packet kernel: at most 72 VGPRs (measured C3: 1.704 ms at 7, 1.706 at 8 with 28 B of scratch, 1.743 at 6, 1.757 unconstrained) */
 #endif
@@ -1466,8 +1469,14 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
             // within 1 m (the reference's blocking test, quirk Q6)": one word, bit 31 = blocked,
             // 0x7fffffff = nothing hit; the bounce itself needs triangle and distance
             if (shadow) {
-                const uint32_t code = (h.tri == HRT_NO_HIT) ? 0x7fffffffu : (h.tri | ((h.t <= 1.f) ? 0x80000000u : 0u));
-                stu(res_blk(P, k), 0u, i4, code);
+                // (tables of fewer than 2^15 - 1 triangles: a HALF word, bit 15 = blocked, 0x7fff = nothing hit)
+                if (T < HRT_HALF_RESULTS_MAX) {
+                    const uint32_t code16 = (h.tri == HRT_NO_HIT) ? 0x7fffu : (h.tri | ((h.t <= 1.f) ? 0x8000u : 0u));
+                    __builtin_amdgcn_raw_buffer_store_b16((short)code16, res_blk(P, k), (int)(i * 2u), 0, 0);
+                } else {
+                    const uint32_t code = (h.tri == HRT_NO_HIT) ? 0x7fffffffu : (h.tri | ((h.t <= 1.f) ? 0x80000000u : 0u));
+                    stu(res_blk(P, k), 0u, i4, code);
+                }
             } else {
                 stu(res_blk(P, k), 0u, i4, h.tri);
                 stf(res_blk(P, k), cap4, i4, h.t);
@@ -1590,10 +1599,20 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                     const float4 rp = l_rx[rx];
                     float d2rx;
                     const F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
-                    const uint32_t code = ldu(res_blk(P, rx), 0u, i4);   // see the trace kernel
-                    uint32_t stri = code & 0x7fffffffu;
-                    const bool near1 = (code >> 31) != 0u;
-                    if (stri == 0x7fffffffu) stri = HRT_NO_HIT;
+                    uint32_t stri;   // the shadow result: see the trace kernel
+                    bool near1;
+                    if (P.num_tri < HRT_HALF_RESULTS_MAX) {
+                        const uint32_t code16 =
+                            (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(res_blk(P, rx), (int)(i * 2u), 0, 0);
+                        stri = code16 & 0x7fffu;
+                        near1 = (code16 >> 15) != 0u;
+                        if (stri == 0x7fffu) stri = HRT_NO_HIT;
+                    } else {
+                        const uint32_t code = ldu(res_blk(P, rx), 0u, i4);
+                        stri = code & 0x7fffffffu;
+                        near1 = (code >> 31) != 0u;
+                        if (stri == 0x7fffffffu) stri = HRT_NO_HIT;
+                    }
                     if (stri != HRT_NO_HIT && stri >= P.num_tri) {   // cannot happen; never fault
                         atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
                         stri = HRT_NO_HIT;

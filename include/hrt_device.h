@@ -151,8 +151,11 @@ typedef struct {
     /* scratch of the stable compaction: survivor counts per 256-entry chunk, and per bounce the
      * sums over every 32 chunks (u32 [num_bounces][num_super]) */
     uint64_t off_chunk_cnt, off_super_cnt;
-    /* trace results of one launch: for trace kind k (0..num_rx-1 shadow to rx k, num_rx the
-     * bounce itself) u32 triangle[cap] then f32 distance[cap] at off_res + (2k, 2k+1)*cap*4 */
+    /* trace results of one launch (internal scratch between the two kernels): for trace kind k
+     * (0..num_rx-1 shadow to rx k, num_rx the bounce itself) a block of 2*cap words at
+     * off_res + 2k*cap*4 -- the bounce: u32 triangle[cap] then f32 distance[cap]; a shadow trace:
+     * one packed word per entry (triangle | blocked << 31), a half word on tables of fewer than
+     * 32 767 triangles (triangle | blocked << 15) */
     uint64_t off_res;
     uint64_t num_super;
     /* re-sorting of the live list between bounces (only when the problem has it on, HRT_SORT_RAYS):
