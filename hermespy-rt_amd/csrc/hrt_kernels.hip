@@ -432,17 +432,21 @@ __device__ __forceinline__ Packet packet_bounds(const Ball &B, F3 d, bool valid,
     Packet P;
     P.bc = B.c;
     P.br = B.r;
+    // (bounds, not reference arithmetic: approximate rsq/sqrt and FMAs, like the culling test)
+    F3 sd;
     if (shadow) {
+        // every ray points at the apex: the direction from the ball's centre is as good an axis as
+        // the mean direction, and costs no reduction (any unit axis is sound: the half-angle below is
+        // measured against whichever is used)
         P.oc = apex;
-        const F3 v = sub3(apex, B.c);
-        const float lmax = fast_sqrt(fdot3(v, v)) * 1.0001f + B.r;
+        sd = sub3(apex, B.c);
+        const float lmax = fast_sqrt(fdot3(sd, sd)) * 1.0001f + B.r;
         P.ro = 8.f * (0.5f * kEps) * lmax + 1e-7f;
     } else {
         P.oc = B.c;
         P.ro = B.r;
+        sd = wave_sum3({valid ? d.x : 0.f, valid ? d.y : 0.f, valid ? d.z : 0.f});
     }
-    const F3 sd = wave_sum3({valid ? d.x : 0.f, valid ? d.y : 0.f, valid ? d.z : 0.f});
-    // (bounds, not reference arithmetic: approximate rsq/sqrt and FMAs, like the culling test)
     const float n2 = fdot3(sd, sd);
     const float inv = fast_rsq(fmaxf(n2, 1e-30f));
     P.ax = {sd.x * inv, sd.y * inv, sd.z * inv};
@@ -606,7 +610,8 @@ __device__ __forceinline__ uint32_t rxt_cell(F3 a)
     float major = a.x, c1 = a.y, c2 = a.z;
     if (ay > ax && ay >= az) { m = 1u; major = a.y; c1 = a.z; c2 = a.x; }
     else if (az > ax && az > ay) { m = 2u; major = a.z; c1 = a.x; c2 = a.y; }
-    const float inv = 1.f / major;
+    // (1 ulp: the host widens every cell's cone by 3e-4 rad for the rounding of this lookup)
+    const float inv = __builtin_amdgcn_rcpf(major);
     const float u = c1 * inv, v = c2 * inv;
     int iu = (int)((u * 0.5f + 0.5f) * (float)HRT_RXT_N), iv = (int)((v * 0.5f + 0.5f) * (float)HRT_RXT_N);
     iu = iu < 0 ? 0 : (iu > HRT_RXT_N - 1 ? HRT_RXT_N - 1 : iu);
