@@ -1,0 +1,55 @@
+"""Exhaustive comparison of the incidence angle -- fold((float)acos((double)x)), src/compute_paths.c:281-283
+-- as the DEVICE computes it against the host libm the reference calls, over EVERY float x with
+|x| <= 1 (2 x 1 065 353 217 inputs; beyond 1 both sides give NaN, sampled).  Run on the GPU box:
+
+    python tests/exhaustive_incidence.py            # prints every input on which the two differ
+
+The device's double acos is the ROCm device library's, the host's is glibc's; both are within an ulp
+of the true value, so the floats they round to differ only where the true value lies within ~1e-16
+of a rounding boundary: a handful of inputs, which the kernel carries as an exception table
+(kIncidenceFix in csrc/hrt_kernels.hip).  tests/test_gpu_libm.py runs this as a test."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hermespy_rt_amd import lib       # noqa: E402
+from oracle import oracle              # noqa: E402
+
+ONE = 0x3F800000
+
+
+def device_eval(L, fn, x):
+    out = np.empty_like(x)
+    f32p = C.POINTER(C.c_float)
+    lib.check(L.hrt_selftest_math(0, fn, x.ctypes.data_as(f32p), out.ctypes.data_as(f32p), x.size),
+              "hrt_selftest_math")
+    return out
+
+
+def mismatches(L, chunk=1 << 26, lo=0, hi=ONE + 1, progress=False):
+    """[(x bits, device bits, host bits)] over the bit patterns lo..hi-1 and their negatives"""
+    bad = []
+    for sign in (0, 0x80000000):
+        for a in range(lo, hi, chunk):
+            b = min(hi, a + chunk)
+            u = (np.arange(a, b, dtype=np.uint64) | sign).astype(np.uint32)
+            x = u.view(np.float32)
+            got = device_eval(L, 4, x)
+            ref = oracle.host_libm("incidence_angle", x)
+            ne = (got.view(np.uint32) != ref.view(np.uint32)) & ~(np.isnan(got) & np.isnan(ref))
+            for k in np.flatnonzero(ne):
+                bad.append((int(u[k]), int(got.view(np.uint32)[k]), int(ref.view(np.uint32)[k])))
+            if progress:
+                print("sign %d  %08x..%08x  mismatches so far %d" % (sign >> 31, a, b, len(bad)), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    L = lib.load()
+    bad = mismatches(L, progress=True)
+    print("EXHAUSTIVE incidence angle: %d inputs differ" % len(bad))
+    for xb, g, r in bad:
+        print("  x=0x%08x (%r)  device=0x%08x  host=0x%08x" % (xb, float(np.uint32(xb).view(np.float32)), g, r))

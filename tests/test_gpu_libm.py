@@ -1,6 +1,7 @@
 """The device's float libm restatements (csrc/hrt_libm.h) evaluated ON THE GPU against the
 host libm the reference calls: bit-exact on a dense sample of the domain the tracer produces
-(the exhaustive host-side pin is oracle/libm_probe --full)."""
+(the exhaustive host-side pin is oracle/libm_probe --full), and the double-precision incidence
+angle on EVERY float input."""
 import ctypes as C
 
 import numpy as np
@@ -60,16 +61,15 @@ def test_device_libm_bit_exact(product_lib, name):
     assert same.all(), "%s: %d of %d differ, e.g. x=%r" % (name, (~same).sum(), x.size, x[~same][:3])
 
 
-def test_incidence_angle_double_acos(product_lib):
-    """acos in double (device library vs glibc) rounded to float: equal except, rarely, by one
-    float ulp (documented residual)."""
-    x = _floats(0.0, 1.0000001, 101)
+def test_incidence_angle_exhaustive(product_lib):
+    """acos in double (device library vs glibc) rounded to float and folded (src/compute_paths.c:
+    281-283): a function of ONE float, so compared on EVERY float with |x| <= 1 -- 2.13e9 inputs,
+    bit for bit (tests/exhaustive_incidence.py) -- and on a sample beyond 1 (NaN on both sides)."""
+    from tests.exhaustive_incidence import mismatches, ONE
+    bad = mismatches(product_lib)
+    assert not bad, "%d inputs differ, e.g. %s" % (len(bad), ["x=0x%08x dev=0x%08x host=0x%08x" % t for t in bad[:5]])
+    x = _floats(1.0000001, 3.0e38, 100003)
     got = _device_eval(product_lib, 4, x)
     ref = oracle.host_libm("incidence_angle", x)
-    diff = got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)
-    nan = np.isnan(ref)
-    assert np.array_equal(np.isnan(got), nan)
-    assert np.abs(diff[~nan]).max() <= 1
-    frac = float((diff[~nan] != 0).mean())
-    print("incidence angle: %d inputs, %.3g differ by 1 ulp" % (x.size, frac))
-    assert frac < 1e-6
+    assert np.isnan(got).all() and np.isnan(ref).all()
+    assert ONE == 0x3F800000
