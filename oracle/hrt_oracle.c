@@ -281,6 +281,17 @@ static inline void st3(float *p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 
 int hrt_oracle_version(void) { return 1; }
 
+/* cap on the threads of every parallel region (a container may show all the machine's cores
+ * while owning a share of them: oracle.py passes min(16, cores)) */
+void hrt_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int hrt_oracle_max_threads(void)
 {
 #ifdef _OPENMP

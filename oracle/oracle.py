@@ -67,6 +67,15 @@ def lib():
             C.POINTER(_Chan), C.POINTER(_Rays), C.POINTER(_Chan), C.POINTER(_Rays),
             C.POINTER(_Opts)]
         _lib.hrt_oracle_max_threads.restype = C.c_int
+        # a GPU box shows all 256 cores of its host to a container that owns 16 of them: 256 OpenMP
+        # threads there mean barriers between descheduled threads (HRT_ORACLE_THREADS overrides)
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        _lib.hrt_oracle_set_threads.argtypes = [C.c_int]
+        _lib.hrt_oracle_set_threads.restype = None
+        _lib.hrt_oracle_set_threads(int(os.environ.get("HRT_ORACLE_THREADS", min(16, cores))))
         _lib.hrt_oracle_libm.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t]
         _lib.hrt_oracle_libm.restype = None
     return _lib

@@ -3,6 +3,9 @@
 |x| <= 1 (2 x 1 065 353 217 inputs; beyond 1 both sides give NaN, sampled).  Run on the GPU box:
 
     python tests/exhaustive_incidence.py            # prints every input on which the two differ
+    python tests/exhaustive_incidence.py sinf cosf sincosf.sin sincosf.cos cosf_nb expf acosf
+                                                    # the same for the float libm restatements of
+                                                    # csrc/hrt_libm.h ON THE DEVICE, over their domains
 
 The device's double acos is the ROCm device library's, the host's is glibc's; both are within an ulp
 of the true value, so the floats they round to differ only where the true value lies within ~1e-16
@@ -29,7 +32,19 @@ def device_eval(L, fn, x):
     return out
 
 
-def mismatches(L, chunk=1 << 26, lo=0, hi=ONE + 1, progress=False):
+# the float libm restatements of csrc/hrt_libm.h over the domains the tracer can reach (the same as
+# oracle/libm_probe --full pins on the host): name -> (device selftest code, host function, end of the
+# domain as a float bit pattern)
+LIBM = {
+    "sinf": (0, "sinf", 0x42F00000), "cosf": (1, "cosf", 0x42F00000),          # |x| < 120
+    "sincosf.sin": (5, "sinf", 0x42F00000), "sincosf.cos": (6, "cosf", 0x42F00000),
+    "cosf_nb": (7, "cosf", 0x42F00000),
+    "expf": (2, "expf", 0x42B00000),                                           # |x| < 88
+    "acosf": (3, "acosf", ONE + 1),                                            # |x| <= 1
+}
+
+
+def mismatches(L, chunk=1 << 26, lo=0, hi=ONE + 1, progress=False, code=4, host="incidence_angle"):
     """[(x bits, device bits, host bits)] over the bit patterns lo..hi-1 and their negatives"""
     bad = []
     for sign in (0, 0x80000000):
@@ -37,8 +52,8 @@ def mismatches(L, chunk=1 << 26, lo=0, hi=ONE + 1, progress=False):
             b = min(hi, a + chunk)
             u = (np.arange(a, b, dtype=np.uint64) | sign).astype(np.uint32)
             x = u.view(np.float32)
-            got = device_eval(L, 4, x)
-            ref = oracle.host_libm("incidence_angle", x)
+            got = device_eval(L, code, x)
+            ref = oracle.host_libm(host, x)
             ne = (got.view(np.uint32) != ref.view(np.uint32)) & ~(np.isnan(got) & np.isnan(ref))
             for k in np.flatnonzero(ne):
                 bad.append((int(u[k]), int(got.view(np.uint32)[k]), int(ref.view(np.uint32)[k])))
@@ -49,7 +64,13 @@ def mismatches(L, chunk=1 << 26, lo=0, hi=ONE + 1, progress=False):
 
 if __name__ == "__main__":
     L = lib.load()
-    bad = mismatches(L, progress=True)
-    print("EXHAUSTIVE incidence angle: %d inputs differ" % len(bad))
-    for xb, g, r in bad:
-        print("  x=0x%08x (%r)  device=0x%08x  host=0x%08x" % (xb, float(np.uint32(xb).view(np.float32)), g, r))
+    which = sys.argv[1:] or ["incidence_angle"]
+    for name in which:
+        if name == "incidence_angle":
+            bad = mismatches(L, progress=True)
+        else:
+            code, host, end = LIBM[name]
+            bad = mismatches(L, hi=end, code=code, host=host, progress=True)
+        print("EXHAUSTIVE %s: %d inputs differ" % (name, len(bad)))
+        for xb, g, r in bad[:50]:
+            print("  x=0x%08x (%r)  device=0x%08x  host=0x%08x" % (xb, float(np.uint32(xb).view(np.float32)), g, r))
