@@ -98,7 +98,8 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
     const char *off_env = getenv("HRT_NO_RXT"), *notx_env = getenv("HRT_NO_TXT");
     uint32_t max_tri = HRT_RXT_MAX_TRI;
     { const char *mv = getenv("HRT_RXT_MAX_TRI"); if (mv && *mv) max_tri = (uint32_t)atol(mv); if (max_tri > 65535u) max_tri = 65535u; }
-    if (T == 0 || T > max_tri || n_rx > 64 || (off_env && *off_env && *off_env != '0')) return HRT_OK;
+    /* (up to 64 triangles the whole table is ONE culling round: a list cannot be cheaper) */
+    if (T <= 64 || T > max_tri || n_rx > 64 || (off_env && *off_env && *off_env != '0')) return HRT_OK;
     const uint32_t n_txt = (n_rx + p->num_tx <= 64 && !(notx_env && *notx_env && *notx_env != '0')) ? p->num_tx : 0u;
     const uint32_t nrx = n_rx + n_txt;
     /* the ball every ray origin lies in: hit points are on triangles (+ 1e-4 along the new direction) */
