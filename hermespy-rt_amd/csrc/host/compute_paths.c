@@ -160,6 +160,9 @@ static void work_free(work_t *w)
     free(w->dirs_batch); free(w->cur_rays); free(w->active); free(w->next_active);
 }
 
+#ifndef HRT_SCATTER_AHEAD
+#define HRT_SCATTER_AHEAD 64u
+#endif
 typedef struct {
     const hrt_shard *s;
     const uint32_t *ray;
@@ -192,15 +195,36 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     const float *r0 = c->rec[HRT_REC_A_TE_RE], *r1 = c->rec[HRT_REC_A_TE_IM], *r2 = c->rec[HRT_REC_A_TM_RE],
                 *r3 = c->rec[HRT_REC_A_TM_IM], *r4 = c->rec[HRT_REC_TAU], *r5 = c->rec[HRT_REC_DIRX],
                 *r6 = c->rec[HRT_REC_DIRY], *r7 = c->rec[HRT_REC_DIRZ], *r8 = c->rec[HRT_REC_DFS];
-    for (uint64_t i = c->i_base + i0; i < c->i_base + i1; ++i) {
-        uint64_t ql = c->ray[i];
-        size_t tx = 0;
-        if (c->ntx > 1) { tx = ql / n_loc; ql -= tx * n_loc; }
-        uint64_t p;
-        if (count == 1) p = ql;
-        else if (ch_pow2) p = (((ql >> sh) * count + rank) << sh) + (ql & (ch - 1u));
-        else p = ((ql / ch) * count + rank) * ch + ql % ch;
-        const size_t off = ((c->rx * c->ntx + tx) * c->nb + c->b) * c->np + p;
+    /* The slots of consecutive records are scattered over a window of the dense arrays (the launch
+     * order walks a z-band of 32 768 paths by azimuth, not by path index: 128 KB per array, seven
+     * arrays): most stores miss the near caches, so the lines of the record HRT_SCATTER_AHEAD entries
+     * on are requested for ownership now (its slot arithmetic is repeated: cheaper than the misses it
+     * hides; warm C3 readback 39-42 -> 33 ms; 16 ... 128 entries ahead measure the same within noise, 4
+     * and 8 gain nothing).  Ordering each window of 8 192 records by slot first -- sequential stores,
+     * random loads from the staging -- was slower than either (48 ms). */
+#define SLOT_OF(I, OFF)                                                                          \
+    do {                                                                                         \
+        uint64_t ql_ = c->ray[(I)];                                                              \
+        size_t tx_ = 0;                                                                          \
+        if (c->ntx > 1) { tx_ = ql_ / n_loc; ql_ -= tx_ * n_loc; }                               \
+        uint64_t p_;                                                                             \
+        if (count == 1) p_ = ql_;                                                                \
+        else if (ch_pow2) p_ = (((ql_ >> sh) * count + rank) << sh) + (ql_ & (ch - 1u));         \
+        else p_ = ((ql_ / ch) * count + rank) * ch + ql_ % ch;                                   \
+        (OFF) = ((c->rx * c->ntx + tx_) * c->nb + c->b) * c->np + p_;                            \
+    } while (0)
+    const uint64_t i_end = c->i_base + i1;
+    for (uint64_t i = c->i_base + i0; i < i_end; ++i) {
+        if (i + HRT_SCATTER_AHEAD < i_end) {
+            size_t offp;
+            SLOT_OF(i + HRT_SCATTER_AHEAD, offp);
+            __builtin_prefetch(&a0[offp], 1, 1); __builtin_prefetch(&a1[offp], 1, 1);
+            __builtin_prefetch(&a2[offp], 1, 1); __builtin_prefetch(&a3[offp], 1, 1);
+            __builtin_prefetch(&tau[offp], 1, 1); __builtin_prefetch(&drx[offp], 1, 1);
+            __builtin_prefetch(&fs[offp], 1, 1);
+        }
+        size_t off;
+        SLOT_OF(i, off);
         a0[off] = r0[i];
         a1[off] = r1[i];
         a2[off] = r2[i];
@@ -212,6 +236,7 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
             ++unb;
         }
     }
+#undef SLOT_OF
     c->unblocked[tid] += unb;
 }
 
@@ -232,7 +257,12 @@ static void q10_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     const hrt_shard *s = c->s;
     const uint32_t ch = s->chunk ? s->chunk : 4096u;
     const uint64_t count = s->count, rank = s->rank;
-    for (uint64_t i = c->i_base + i0; i < c->i_base + i1; ++i) {
+    const uint64_t i_end = c->i_base + i1;
+    for (uint64_t i = c->i_base + i0; i < i_end; ++i) {
+        if (i + HRT_SCATTER_AHEAD < i_end) {   /* as in scatter_range */
+            const uint64_t qa = c->ray[i + HRT_SCATTER_AHEAD] - c->ray_base;
+            __builtin_prefetch(&c->fs_tx[(count == 1) ? qa : ((qa / ch) * count + rank) * ch + qa % ch], 1, 1);
+        }
         const uint64_t ql = c->ray[i] - c->ray_base;
         const uint64_t p = (count == 1) ? ql : ((ql / ch) * count + rank) * ch + ql % ch;
         const float *mv = c->h_mesh + (size_t)c->tri_mesh[c->tri[i]] * HRT_MESH_FLOATS;
