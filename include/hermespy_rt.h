@@ -162,9 +162,10 @@ const char *hrt_last_error(void);
 /* "hermespy-rt_amd <version> (gfx950)" */
 const char *hrt_version(void);
 
-/* compute_paths keeps the launch-direction table (and launch order) of the last num_rays between
- * calls -- they depend on num_rays only; see csrc/host/compute_paths.c.  This frees it.
- * Environment: HRT_NO_CACHE=1 disables the cache. */
+/* Between calls compute_paths keeps: (with HRT_HOST_LAUNCH=1) the launch-direction table and launch
+ * order of the last num_rays; the device workspace and page-locked staging of the last call; and
+ * the calling thread's helper threads of the dense writer, parked (csrc/host/compute_paths.c).
+ * This releases all three.  Environment: HRT_NO_CACHE=1 keeps no buffers. */
 void hrt_cache_clear(void);
 
 #ifdef __cplusplus
