@@ -320,6 +320,15 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     c->unblocked[tid] += unb;
 }
 
+/* a memcpy cut into ranges */
+typedef struct { float *dst; const float *src; } copy_ctx;
+static void copy_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    (void)tid;
+    const copy_ctx *c = (const copy_ctx *)vctx;
+    memcpy(c->dst + i0, c->src + i0, (i1 - i0) * sizeof(float));
+}
+
 /* Q10 adds of one TX run (distinct slots: one per ray), see run_batch */
 typedef struct {
     const hrt_shard *s;
@@ -906,11 +915,19 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             }
         }
         st.t_launch_dirs_s = hrt_now_s() - t0;
-        /* Q9: the two memcpy replications of the launch term */
-        for (size_t b = 1; b < nb; ++b)
-            memcpy(scat->freq_shift + nq * b, scat->freq_shift, nq * sizeof(float));
-        for (size_t rx = 1; rx < nrx; ++rx)
-            memcpy(scat->freq_shift + nq * nb * rx, scat->freq_shift, nq * nb * sizeof(float));
+        /* Q9: the two memcpy replications of the launch term (source and destinations never overlap:
+         * each is cut into ranges for the helper threads -- 240 MB on C3, 7 ms on one thread) */
+        {
+            const int thr = hrt_host_threads();
+            for (size_t b = 1; b < nb; ++b) {
+                copy_ctx cc = {scat->freq_shift + nq * b, scat->freq_shift};
+                hrt_parallel_ranges(copy_range, &cc, nq, thr);
+            }
+            for (size_t rx = 1; rx < nrx; ++rx) {
+                copy_ctx cc = {scat->freq_shift + nq * nb * rx, scat->freq_shift};
+                hrt_parallel_ranges(copy_range, &cc, nq * nb, thr);
+            }
+        }
 
         if (scat_rays) {
             /* :469-471 and :589 */
