@@ -795,7 +795,8 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     }
     /* one problem per device (the scene is tiny; every device holds all of it) */
     for (int d = 0; d < D && !rc; ++d)
-        rc = hrt_problem_create(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, ctx[d].device, &ctx[d].prob);
+        rc = hrt_problem_create_for(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, ctx[d].device,
+                                    (uint64_t)ntx * np / (uint64_t)D, &ctx[d].prob);
     if (rc) goto done;
     hrt_problem *prob = ctx[0].prob;
 

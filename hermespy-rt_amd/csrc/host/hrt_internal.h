@@ -73,6 +73,12 @@ struct hrt_problem {
     float scene_lo[3], scene_hi[3];   /* bounding box of the (finite) vertices */
 };
 
+/* hrt_problem_create with the number of rays the problem will trace (decides whether the direction
+ * tables are worth building: problem.c) */
+int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                           const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t num_rx,
+                           size_t num_tx, int device, uint64_t rays_hint, hrt_problem **out);
+
 /* error plumbing: set the thread's last-error text and return `code` */
 int hrt_fail(int code, const char *fmt, ...);
 int hrt_fail_hip(int hip_err, const char *what);

@@ -138,7 +138,8 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     memset(&st, 0, sizeof st);
     st.device = device;
     hrt_problem *prob = NULL;
-    int rc = hrt_problem_create(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, device, &prob);
+    int rc = hrt_problem_create_for(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, device,
+                                    (uint64_t)ntx * np, &prob);
     if (rc) return rc;
     st.t_setup_s = hrt_now_s() - t_begin;
 

@@ -7,6 +7,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# A one-shot drop-in call builds the per-RX / per-TX direction tables only for launch sets of 2^26 rays
+# or more (they cost more than they save below that: csrc/host/problem.c).  The parity tests want the
+# table path exercised at every size: subprocesses inherit this too.
+os.environ.setdefault("HRT_RXT_MIN_RAYS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

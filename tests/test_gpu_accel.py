@@ -53,8 +53,9 @@ print("ACCEL_OK", len(cases))
     dict(HRT_TRACE_VARIANT="0", HRT_NO_REORDER="1"),
     dict(HRT_NO_TXT="1"),                          # direction tables for the RXs only (default: RXs and TXs)
     dict(HRT_NO_RXT="1"),                          # ... and none at all
+    dict(HRT_RXT_MIN_RAYS="67108864"),             # the drop-in's own default: tables from 2^26 rays on (none here)
 ], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order",
-        "rx_tables_only", "no_tables"])
+        "rx_tables_only", "no_tables", "tables_by_size"])
 def test_modes_are_bit_identical_to_the_oracle(env):
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
