@@ -250,7 +250,7 @@ typedef struct {
     const uint64_t *mask;
     ChannelInfo *scat;
     uint64_t n_loc, i_base;   /* the range handed to scatter_range is relative to i_base */
-    size_t rx, b, ntx, nb, np;
+    size_t rx, b, ntx, nb, np, amp_stride;
     uint64_t unblocked[HRT_MAX_SCATTER_THREADS];
 } scatter_ctx;
 
@@ -270,6 +270,7 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     while ((1u << sh) < ch) ++sh;
     const uint64_t count = s->count, rank = s->rank, n_loc = c->n_loc;
     float *const a0 = scat->a_te_re, *const a1 = scat->a_te_im, *const a2 = scat->a_tm_re, *const a3 = scat->a_tm_im;
+    const size_t as = c->amp_stride;
     float *const tau = scat->tau, *const fs = scat->freq_shift;
     Vec3 *const drx = scat->directions_rx;
     const float *r0 = c->rec[HRT_REC_A_TE_RE], *r1 = c->rec[HRT_REC_A_TE_IM], *r2 = c->rec[HRT_REC_A_TM_RE],
@@ -298,17 +299,17 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
         if (i + HRT_SCATTER_AHEAD < i_end) {
             size_t offp;
             SLOT_OF(i + HRT_SCATTER_AHEAD, offp);
-            __builtin_prefetch(&a0[offp], 1, 1); __builtin_prefetch(&a1[offp], 1, 1);
-            __builtin_prefetch(&a2[offp], 1, 1); __builtin_prefetch(&a3[offp], 1, 1);
+            __builtin_prefetch(&a0[offp * as], 1, 1); __builtin_prefetch(&a1[offp * as], 1, 1);
+            __builtin_prefetch(&a2[offp * as], 1, 1); __builtin_prefetch(&a3[offp * as], 1, 1);
             __builtin_prefetch(&tau[offp], 1, 1); __builtin_prefetch(&drx[offp], 1, 1);
             __builtin_prefetch(&fs[offp], 1, 1);
         }
         size_t off;
         SLOT_OF(i, off);
-        a0[off] = r0[i];
-        a1[off] = r1[i];
-        a2[off] = r2[i];
-        a3[off] = r3[i];
+        a0[off * as] = r0[i];
+        a1[off * as] = r1[i];
+        a2[off * as] = r2[i];
+        a3[off * as] = r3[i];
         tau[off] = r4[i];
         if ((c->mask[i >> 6] >> (i & 63)) & 1u) {
             drx[off] = (Vec3){r5[i], r6[i], r7[i]};
@@ -585,7 +586,8 @@ static int run_batch(dev_ctx *c, uint32_t g)
     /* ---- LoS block (identical in every batch; written once, by the owner of batch 0) :515-577 ---- */
     if (g == 0) {
         DL(w->h_los, L.off_los, nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
-        for (size_t off = 0; off < nrx * ntx; ++off) los->a_te_im[off] = los->a_tm_im[off] = 0.f;
+        const size_t as = c->amp_stride;
+        for (size_t off = 0; off < nrx * ntx; ++off) los->a_te_im[off * as] = los->a_tm_im[off * as] = 0.f;
         for (size_t rx = 0, off = 0; rx < nrx; ++rx)
             for (size_t tx = 0; tx < ntx; ++tx, ++off) {
                 const float *q = w->h_los + HRT_LOS_FLOATS * off;
@@ -602,18 +604,18 @@ static int run_batch(dev_ctx *c, uint32_t g)
                 if (status == 0u) {          /* coincident */
                     los->directions_rx[off] = (Vec3){1.f, 0.f, 0.f};
                     los->directions_tx[off] = (Vec3){-1.f, 0.f, 0.f};
-                    los->a_te_re[off] = los->a_tm_re[off] = 1.f;
+                    los->a_te_re[off * as] = los->a_tm_re[off * as] = 1.f;
                     los->tau[off] = 0.f;
                     los->freq_shift[off] = 0.f;
                     if (los_rays) los_rays->rays_active[off / 8] |= bit;
                 } else if (status == 1u) {   /* blocked: Q3 */
-                    los->a_te_re[off] = los->a_tm_re[off] = los->tau[off] = 0.f;
+                    los->a_te_re[off * as] = los->a_tm_re[off * as] = los->tau[off] = 0.f;
                     if (los_rays) los_rays->rays_active[off / 8] &= (uint8_t)~bit;
                 } else {
                     Vec3 u = {q[HRT_LOS_DIRX], q[HRT_LOS_DIRY], q[HRT_LOS_DIRZ]};
                     los->directions_tx[off] = u;
                     los->directions_rx[off] = (Vec3){-u.x, -u.y, -u.z};
-                    los->a_te_re[off] = los->a_tm_re[off] = q[HRT_LOS_A];
+                    los->a_te_re[off * as] = los->a_tm_re[off * as] = q[HRT_LOS_A];
                     los->tau[off] = q[HRT_LOS_TAU];
                     los->freq_shift[off] = q[HRT_LOS_FS];
                     if (los_rays) los_rays->rays_active[off / 8] |= bit;
@@ -707,6 +709,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
                     memset(&sc, 0, sizeof sc);
                     sc.s = &s; sc.ray = w->ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
                     sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
+                    sc.amp_stride = c->amp_stride;
                     sc.i_base = r0;
                     if (!env_int("HRT_DEBUG_NO_SCATTER", 0))   /* timing experiments: copies only */
                         hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
@@ -759,10 +762,38 @@ static void *worker_main(void *arg)
     return NULL;
 }
 
+static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                              const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t nrx,
+                              size_t ntx, size_t np, size_t nb, ChannelInfo *los, RaysInfo *los_rays,
+                              ChannelInfo *scat, RaysInfo *scat_rays, hrt_stats *stats, size_t amp_stride);
+
 int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                          const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t nrx,
                          size_t ntx, size_t np, size_t nb, ChannelInfo *los, RaysInfo *los_rays,
                          ChannelInfo *scat, RaysInfo *scat_rays, hrt_stats *stats)
+{
+    return compute_paths_impl(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, np, nb, los, los_rays, scat,
+                              scat_rays, stats, 1);
+}
+
+/* The same call for callers whose amplitudes are COMPLEX arrays (numpy complex64, C99 float
+ * _Complex): a_te_re / a_te_im (a_tm_*) point at the real and the imaginary part of element 0,
+ * element i lives at [2 i] of each -- the dense writer then fills the caller's complex arrays in
+ * place instead of four planes that somebody has to interleave afterwards (the pybind module did:
+ * 2 GB of extra passes on C3).  Everything else as hrt_compute_paths_ex. */
+int hrt_compute_paths_interleaved(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                                  const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t nrx,
+                                  size_t ntx, size_t np, size_t nb, ChannelInfo *los, RaysInfo *los_rays,
+                                  ChannelInfo *scat, RaysInfo *scat_rays, hrt_stats *stats)
+{
+    return compute_paths_impl(scene, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nrx, ntx, np, nb, los, los_rays, scat,
+                              scat_rays, stats, 2);
+}
+
+static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                              const Vec3 *rx_vel, const Vec3 *tx_vel, float f_ghz, size_t nrx,
+                              size_t ntx, size_t np, size_t nb, ChannelInfo *los, RaysInfo *los_rays,
+                              ChannelInfo *scat, RaysInfo *scat_rays, hrt_stats *stats, size_t amp_stride)
 {
     const double t_begin = hrt_now_s();
     if (!scene || !los || !scat) return hrt_fail(HRT_E_INVALID, "compute_paths: NULL argument");
@@ -788,6 +819,7 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         c->scene = scene; c->rx_pos = rx_pos; c->tx_pos = tx_pos; c->rx_vel = rx_vel; c->tx_vel = tx_vel;
         c->f_ghz = f_ghz; c->nrx = nrx; c->ntx = ntx; c->np = np; c->nb = nb; c->nq = nq;
         c->los = los; c->scat = scat; c->los_rays = los_rays; c->scat_rays = scat_rays;
+        c->amp_stride = amp_stride;
         c->index = d; c->count = D; c->device = devs[d];
         c->host_launch = env_int("HRT_HOST_LAUNCH", 0);
         int thr = hrt_host_threads() / D;

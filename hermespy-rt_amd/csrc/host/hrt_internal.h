@@ -124,6 +124,8 @@ typedef struct {
     RaysInfo *los_rays, *scat_rays;
     uint32_t G;                 /* batches = round-robin shards of the launch set */
     int host_launch, scatter_threads, use_pool;
+    size_t amp_stride;          /* floats between consecutive amplitude entries: 1 (the reference's planes) or
+                                 * 2 (re/im interleaved: hrt_compute_paths_interleaved) */
     /* this worker */
     int index, count;           /* handles batches index, index + count, ... */
     int device;

@@ -21,16 +21,23 @@
 //   * the RaysInfo buffers the reference allocates (too small, Q13) and then throws away are
 //     not produced at all;
 //   * an unreadable scene file raises ValueError instead of exit(8); tracer errors raise
-//     RuntimeError; the GIL is released while the GPU works.
+//     RuntimeError; the GIL is released while the GPU works;
+//   * the complex amplitudes are written in place (hrt_compute_paths_interleaved) and the arrays
+//     start as untouched zero pages: the reference's binding fills four planes and interleaves them
+//     afterwards (:44-97) -- on C3 those passes were 0.45 s around a 0.04 s call.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "hermespy_rt.h"
 
@@ -55,12 +62,34 @@ const Vec3 *as_vec3(const farr &a, size_t n, const char *name)
     return reinterpret_cast<const Vec3 *>(a.data());
 }
 
+// Output arrays are fresh zero pages behind a capsule -- calloc() for small ones, an anonymous mapping
+// advised to use huge pages for big ones (C3: 2.3 GB): "reads 0 where the reference writes nothing"
+// then costs no pass over the memory, the pages are first touched by the threads of the dense writer
+// that fill them, and with 2 MiB pages those first touches are ~10^3 faults instead of ~6 10^5
+// (py::array_t + memset was 0.3 s of a 0.5 s call on C3).
+struct Mapping { void *p; size_t bytes; };
 template <typename T>
 py::array_t<T> zeros(std::vector<size_t> shape)
 {
-    py::array_t<T> a(shape);
-    std::memset(a.mutable_data(), 0, sizeof(T) * (size_t)a.size());
-    return a;
+    size_t n = 1;
+    for (size_t d : shape) n *= d;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    if (bytes >= ((size_t)4 << 20)) {
+        const size_t huge = (size_t)2 << 20, len = (bytes + huge - 1) & ~(huge - 1);
+        void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(p, len, MADV_HUGEPAGE);   // a hint; plain pages are as correct
+        py::capsule owner(new Mapping{p, len}, [](void *q) {
+            Mapping *m = static_cast<Mapping *>(q);
+            munmap(m->p, m->bytes);
+            delete m;
+        });
+        return py::array_t<T>(shape, static_cast<T *>(p), owner);
+    }
+    T *p = static_cast<T *>(std::calloc(n ? n : 1, sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    py::capsule owner(p, [](void *q) { std::free(q); });
+    return py::array_t<T>(shape, p, owner);
 }
 
 void check_scene_file(const std::string &path)
@@ -74,39 +103,29 @@ void check_scene_file(const std::string &path)
         throw py::value_error("not an HRT scene file: " + path);
 }
 
-// one channel block: float32 outputs are written in place; the complex amplitudes go through
-// re/im planes because the C ABI wants them separate
+// one channel block: every output is written in place by the library -- the complex amplitudes too,
+// through hrt_compute_paths_interleaved (re at [2 i], im at [2 i + 1] of the complex64 arrays)
 struct ChannelBuffers {
     ChannelInfoPy out;
-    std::vector<float> te_re, te_im, tm_re, tm_im;
     ChannelInfo c{};
     ChannelBuffers(size_t nrx, size_t ntx, size_t n)
-        : te_re(nrx * ntx * n), te_im(nrx * ntx * n), tm_re(nrx * ntx * n), tm_im(nrx * ntx * n)
     {
         out.num_paths = n;
         out.directions_rx = zeros<float>({nrx, ntx, n, 3});
         out.directions_tx = zeros<float>({nrx, ntx, n, 3});
+        out.a_te = zeros<std::complex<float>>({nrx, ntx, n});
+        out.a_tm = zeros<std::complex<float>>({nrx, ntx, n});
         out.tau = zeros<float>({nrx, ntx, n});
         out.freq_shift = zeros<float>({nrx, ntx, n});
         c.num_rays = (uint32_t)n;
         c.directions_rx = reinterpret_cast<Vec3 *>(out.directions_rx.mutable_data());
         c.directions_tx = reinterpret_cast<Vec3 *>(out.directions_tx.mutable_data());
-        c.a_te_re = te_re.data(); c.a_te_im = te_im.data();
-        c.a_tm_re = tm_re.data(); c.a_tm_im = tm_im.data();
+        float *te = reinterpret_cast<float *>(out.a_te.mutable_data());
+        float *tm = reinterpret_cast<float *>(out.a_tm.mutable_data());
+        c.a_te_re = te; c.a_te_im = te + 1;
+        c.a_tm_re = tm; c.a_tm_im = tm + 1;
         c.tau = out.tau.mutable_data();
         c.freq_shift = out.freq_shift.mutable_data();
-    }
-    void finish(size_t nrx, size_t ntx, size_t n)
-    {
-        out.a_te = py::array_t<std::complex<float>>(std::vector<size_t>{nrx, ntx, n});
-        out.a_tm = py::array_t<std::complex<float>>(std::vector<size_t>{nrx, ntx, n});
-        auto *te = out.a_te.mutable_data();
-        auto *tm = out.a_tm.mutable_data();
-        for (size_t i = 0; i < nrx * ntx * n; ++i) {
-            te[i] = {te_re[i], te_im[i]};
-            tm[i] = {tm_re[i], tm_im[i]};
-        }
-        te_re = {}; te_im = {}; tm_re = {}; tm_im = {};
     }
 };
 
@@ -129,17 +148,15 @@ std::tuple<ChannelInfoPy, ChannelInfoPy> compute_paths_py(
     {
         py::gil_scoped_release nogil;
         Scene scene = scene_load(mesh_filepath.c_str());
-        rc = hrt_compute_paths_ex(&scene, rxp, txp, rxv, txv, carrier_frequency, num_rx, num_tx,
-                                  num_paths, num_bounces, &los.c, nullptr, &scat.c, nullptr,
-                                  nullptr);
+        rc = hrt_compute_paths_interleaved(&scene, rxp, txp, rxv, txv, carrier_frequency, num_rx, num_tx,
+                                           num_paths, num_bounces, &los.c, nullptr, &scat.c, nullptr,
+                                           nullptr);
         if (rc != HRT_OK) err = hrt_last_error();
         free_scene(&scene);
     }
     if (rc != HRT_OK)
         throw std::runtime_error("hermespy_rt.compute_paths failed (" + std::to_string(rc) +
                                  "): " + err);
-    los.finish(num_rx, num_tx, 1);
-    scat.finish(num_rx, num_tx, num_bounces * num_paths);
     return {std::move(los.out), std::move(scat.out)};
 }
 

@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libhermespy_rt_amd.so")
 
 #: every symbol include/hermespy_rt.h and include/hrt_device.h declare
 EXPORTED = (
-    "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_compute_paths_list",
-    "hrt_path_list_free", "hrt_last_error",
+    "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_compute_paths_interleaved",
+    "hrt_compute_paths_list", "hrt_path_list_free", "hrt_last_error",
     "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_problem_tri_order", "hrt_shard_num_local",
@@ -94,6 +94,8 @@ def load():
         C.POINTER(abi.Scene), V3, V3, V3, V3, C.c_float, C.c_size_t, C.c_size_t, C.c_size_t,
         C.c_size_t, C.POINTER(abi.ChannelInfo), C.POINTER(abi.RaysInfo),
         C.POINTER(abi.ChannelInfo), C.POINTER(abi.RaysInfo), C.POINTER(Stats)]
+    L.hrt_compute_paths_interleaved.restype = C.c_int
+    L.hrt_compute_paths_interleaved.argtypes = L.hrt_compute_paths_ex.argtypes
     L.hrt_problem_create.restype = C.c_int
     L.hrt_problem_create.argtypes = [C.POINTER(abi.Scene), V3, V3, V3, V3, C.c_float, C.c_size_t,
                                      C.c_size_t, C.c_int, C.POINTER(vp)]

@@ -120,6 +120,18 @@ int hrt_compute_paths_ex(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                          ChannelInfo *chanInfo_los, RaysInfo *raysInfo_los,
                          ChannelInfo *chanInfo_scat, RaysInfo *raysInfo_scat, hrt_stats *stats);
 
+/* hrt_compute_paths_ex for callers whose amplitudes are COMPLEX arrays (numpy complex64, C99 float
+ * _Complex): a_te_re / a_te_im (a_tm_re / a_tm_im) of both ChannelInfo point at the real and the
+ * imaginary part of element 0 of an interleaved array, element i being at [2 i] of each pointer.
+ * The dense writer fills the complex arrays in place (the reference's planes would have to be
+ * interleaved by the binding afterwards: compute_paths_pybind11.cpp:44-97 does).  Everything else
+ * -- arguments, layout quirks, errors -- as hrt_compute_paths_ex. */
+int hrt_compute_paths_interleaved(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
+                                  const Vec3 *rx_vel, const Vec3 *tx_vel, float carrier_frequency_GHz,
+                                  size_t num_rx, size_t num_tx, size_t num_rays, size_t num_bounces,
+                                  ChannelInfo *chanInfo_los, RaysInfo *raysInfo_los,
+                                  ChannelInfo *chanInfo_scat, RaysInfo *raysInfo_scat, hrt_stats *stats);
+
 #define HRT_OK 0
 #define HRT_E_INVALID (-1)   /* bad argument (zero count, material_index > 16, ...) */
 #define HRT_E_NOMEM (-2)     /* host allocation failed */

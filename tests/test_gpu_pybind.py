@@ -95,3 +95,29 @@ def test_compute_paths_list_matches_the_dense_result(rt):
     assert both["rx"].size > n and int(both["unblocked"].sum()) == n
     blk = ~both["unblocked"]
     assert not both["a_te"][blk].any() and not both["tau"][blk].any()
+
+
+@pytest.mark.parametrize("name", ["C3_20k", "C4_DOPPLER_5k"])
+def test_complex_amplitudes_written_in_place(rt, product_lib, name):
+    """The module hands its complex64 arrays to hrt_compute_paths_interleaved (re at [2 i], im at
+    [2 i + 1]); the reference's binding fills four planes and interleaves them
+    (compute_paths_pybind11.cpp:44-97).  Same bits as the planes of hrt_compute_paths_ex, LoS
+    block included; slots nobody writes read 0."""
+    from hermespy_rt_amd import abi
+    c = K.small(K.C3, 20000) if name == "C3_20k" else K.small(K.C4_DOPPLER, 5000)
+    f32 = lambda a: np.array(a, np.float32)   # noqa: E731
+    los, scat = rt.compute_paths(c["scene_path"], f32(c["rx_pos"]), f32(c["tx_pos"]), f32(c["rx_vel"]),
+                                 f32(c["tx_vel"]), c["f_ghz"], len(c["rx_pos"]), len(c["tx_pos"]),
+                                 c["num_paths"], c["num_bounces"])
+    ref = abi.run_compute_paths(product_lib, *K.args(c))
+    for blk, got in (("los", los), ("scat", scat)):
+        for pol in ("a_te", "a_tm"):
+            w = abi.written(ref[blk][pol + "_re"])
+            re = np.where(w, ref[blk][pol + "_re"], np.float32(0)).astype(np.float32)
+            im = np.where(abi.written(ref[blk][pol + "_im"]), ref[blk][pol + "_im"], np.float32(0)).astype(np.float32)
+            g = np.ascontiguousarray(getattr(got, pol)).reshape(-1)
+            assert g.dtype == np.complex64
+            assert np.array_equal(g.real.view(np.uint32), re.reshape(-1).view(np.uint32)), (blk, pol, "re")
+            assert np.array_equal(g.imag.view(np.uint32), im.reshape(-1).view(np.uint32)), (blk, pol, "im")
+        tau = np.where(abi.written(ref[blk]["tau"]), ref[blk]["tau"], np.float32(0)).astype(np.float32)
+        assert np.array_equal(np.ascontiguousarray(got.tau).reshape(-1).view(np.uint32), tau.reshape(-1).view(np.uint32))
