@@ -34,7 +34,10 @@
 #include <cstring>
 #include <new>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <sys/mman.h>
@@ -183,8 +186,17 @@ py::dict compute_paths_list_py(const std::string &mesh_filepath, farr rx_positio
     const Vec3 *rxv = as_vec3(rx_velocities, num_rx, "rx_velocities");
     const Vec3 *txv = as_vec3(tx_velocities, num_tx, "tx_velocities");
     check_scene_file(mesh_filepath);
-    hrt_path_list pl;
-    std::memset(&pl, 0, sizeof pl);
+    // the list stays where the library built it: every numpy array is a view of one of its fields
+    // and keeps it alive through one shared capsule (copying 1.3 GB of fields was 0.19 s of a
+    // 0.24 s call on C3); only the complex amplitudes are formed here, from the re/im planes
+    hrt_path_list *plp = new hrt_path_list;
+    std::memset(plp, 0, sizeof *plp);
+    py::capsule owner(plp, [](void *q) {
+        hrt_path_list *p = static_cast<hrt_path_list *>(q);
+        hrt_path_list_free(p);
+        delete p;
+    });
+    hrt_path_list &pl = *plp;
     int rc;
     std::string err;
     {
@@ -199,26 +211,40 @@ py::dict compute_paths_list_py(const std::string &mesh_filepath, farr rx_positio
         throw std::runtime_error("hermespy_rt.compute_paths_list failed (" + std::to_string(rc) +
                                  "): " + err);
     const size_t n = (size_t)pl.num;
-    py::dict d;
-    d["rx"] = copy_out(pl.rx, {n});
-    d["tx"] = copy_out(pl.tx, {n});
-    d["bounce"] = copy_out(pl.bounce, {n});
-    d["path"] = copy_out(pl.path, {n});
-    py::array_t<std::complex<float>> te(std::vector<size_t>{n}), tm(std::vector<size_t>{n});
-    for (size_t i = 0; i < n; ++i) {
-        te.mutable_data()[i] = {pl.a_te_re[i], pl.a_te_im[i]};
-        tm.mutable_data()[i] = {pl.a_tm_re[i], pl.a_tm_im[i]};
+    py::array_t<std::complex<float>> te = zeros<std::complex<float>>({n}), tm = zeros<std::complex<float>>({n});
+    {
+        py::gil_scoped_release nogil;
+        std::complex<float> *pte = te.mutable_data(), *ptm = tm.mutable_data();
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(8, n / 1000000));
+        std::vector<std::thread> th;
+        auto part = [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; ++i) {
+                pte[i] = {pl.a_te_re[i], pl.a_te_im[i]};
+                ptm[i] = {pl.a_tm_re[i], pl.a_tm_im[i]};
+            }
+        };
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(part, n * k / nt, n * (k + 1) / nt);
+        part(0, n / nt);
+        for (auto &x : th) x.join();
     }
+    auto view = [&](auto *ptr, std::vector<size_t> shape) {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(ptr)>>;
+        return py::array_t<T>(shape, ptr, owner);
+    };
+    py::dict d;
+    d["rx"] = view(pl.rx, {n});
+    d["tx"] = view(pl.tx, {n});
+    d["bounce"] = view(pl.bounce, {n});
+    d["path"] = view(pl.path, {n});
     d["a_te"] = te;
     d["a_tm"] = tm;
-    d["tau"] = copy_out(pl.tau, {n});
-    d["direction_rx"] = copy_out(reinterpret_cast<const float *>(pl.direction_rx), {n, 3});
-    d["freq_shift"] = copy_out(pl.freq_shift, {n});
-    d["unblocked"] = copy_out(reinterpret_cast<const bool *>(pl.unblocked), {n});
-    d["mesh"] = copy_out(pl.mesh, {n});
-    d["face"] = copy_out(pl.face, {n});
-    d["los"] = copy_out(pl.los, {(size_t)num_rx, (size_t)num_tx, (size_t)8});
-    hrt_path_list_free(&pl);
+    d["tau"] = view(pl.tau, {n});
+    d["direction_rx"] = view(reinterpret_cast<float *>(pl.direction_rx), {n, 3});
+    d["freq_shift"] = view(pl.freq_shift, {n});
+    d["unblocked"] = view(reinterpret_cast<bool *>(pl.unblocked), {n});
+    d["mesh"] = view(pl.mesh, {n});
+    d["face"] = view(pl.face, {n});
+    d["los"] = view(pl.los, {(size_t)num_rx, (size_t)num_tx, (size_t)8});
     return d;
 }
 

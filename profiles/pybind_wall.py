@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of the drop-in PYTHON call hermespy_rt.compute_paths() on a named workload (GPU box):
-    python profiles/pybind_wall.py [c3] [repeats]"""
+    python profiles/pybind_wall.py [c3] [repeats] [list]"""
 import os
 import sys
 import time
@@ -28,3 +28,11 @@ for k in range(reps):
     nz = int(np.count_nonzero(scat.a_te))
     print("call %d: %.3f s  (%s; non-zero a_te %d)" % (k, dt, W.describe(c), nz), flush=True)
     del los, scat
+for k in range(reps if "list" in sys.argv else 0):
+    t0 = time.perf_counter()
+    P = hermespy_rt.compute_paths_list(c["scene_path"], f32(c["rx_pos"]), f32(c["tx_pos"]), f32(c["rx_vel"]),
+                                       f32(c["tx_vel"]), c["f_ghz"], len(c["rx_pos"]), len(c["tx_pos"]),
+                                       c["num_paths"], c["num_bounces"])
+    dt = time.perf_counter() - t0
+    print("list call %d: %.3f s  (%d records)" % (k, dt, P["rx"].size), flush=True)
+    del P
