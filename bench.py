@@ -427,8 +427,29 @@ def main():
             out["end_to_end"] = dict(
                 what="hrt_compute_paths_ex (the drop-in C ABI behind compute_paths): host arrays in, the "
                      "reference's dense arrays out; cold = first call in this process after the bench "
-                     "(HIP already initialised), warm = second call",
+                     "(HIP already initialised), warm = second call; python_module_s = wall of "
+                     "hermespy_rt.compute_paths() (the pybind11 drop-in: array allocation, the call, complex "
+                     "amplitudes), second and third call",
                 cold=cold, warm=warm)
+            try:   # the Python surface HermesPy imports
+                import hermespy_rt_amd as _pkg
+                if _pkg.LIB_DIR not in sys.path:
+                    sys.path.insert(0, _pkg.LIB_DIR)
+                import hermespy_rt as _mod
+                import numpy as _np
+                f32 = lambda a: _np.array(a, dtype=_np.float32)   # noqa: E731
+                walls = []
+                for _ in range(3):
+                    p0 = time.perf_counter()
+                    r_ = _mod.compute_paths(base["scene_path"], f32(base["rx_pos"]), f32(base["tx_pos"]),
+                                            f32(base["rx_vel"]), f32(base["tx_vel"]), base["f_ghz"],
+                                            len(base["rx_pos"]), len(base["tx_pos"]), base["num_paths"],
+                                            base["num_bounces"])
+                    walls.append(time.perf_counter() - p0)
+                    del r_
+                out["end_to_end"]["python_module_s"] = walls[1:]
+            except Exception as e:   # the module is optional at build time
+                out["end_to_end"]["python_module_error"] = repr(e)
         except Exception as e:
             out["end_to_end_error"] = repr(e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
