@@ -65,3 +65,35 @@ def test_warm_calls_reuse_pooled_buffers(product_lib):
     got = abi.run_compute_paths(product_lib, *K.args(b))
     st = compare_dense(got, oracle.compute_paths(*K.args(b)))
     assert all(v == 0 for v in st.values()), st
+
+
+def test_many_calls_reuse_the_parked_helper_threads(product_lib):
+    """The dense writer's helper threads are parked between its loops and between calls (per calling
+    thread): many calls of changing size and thread count, dense and list, must neither hang nor drift
+    from the oracle; hrt_cache_clear() in between ends the helpers, and the next call starts new ones."""
+    import os
+    from hermespy_rt_amd import abi
+    from oracle import oracle
+    from . import configs as K
+    from .parity import compare_dense
+    big = K.small(K.C3, 300000)      # several 65 536-record ranges per block: the helpers are used
+    small = K.small(K.C1, 500)       # one range: the calling thread alone
+    ref_big = oracle.compute_paths(*K.args(big))
+    ref_small = oracle.compute_paths(*K.args(small))
+    old = os.environ.get("HRT_HOST_THREADS")
+    try:
+        for k in range(12):
+            os.environ["HRT_HOST_THREADS"] = str((4, 16, 7, 32)[k % 4])
+            c, ref = (big, ref_big) if k % 3 != 2 else (small, ref_small)
+            st = compare_dense(abi.run_compute_paths(product_lib, *K.args(c)), ref)
+            assert all(v == 0 for v in st.values()), (k, st)
+            if k % 4 == 1:
+                pl = abi.run_compute_paths_list(product_lib, *K.args(big))
+                assert pl["rx"].size > 0
+            if k % 5 == 4:
+                product_lib.hrt_cache_clear()
+    finally:
+        if old is None:
+            os.environ.pop("HRT_HOST_THREADS", None)
+        else:
+            os.environ["HRT_HOST_THREADS"] = old
