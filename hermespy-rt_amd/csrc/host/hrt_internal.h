@@ -147,6 +147,7 @@ void hrt_worker_release(dev_ctx *c);  /* back to the pool (when c->rc == HRT_OK)
 typedef void (*hrt_range_fn)(void *ctx, uint64_t i0, uint64_t i1, int tid);
 void hrt_parallel_ranges(hrt_range_fn fn, void *ctx, uint64_t n, int threads);   /* tid < 32 */
 int hrt_host_threads(void);                      /* HRT_HOST_THREADS or min(16, cores) */
+void hrt_parallel_release(void);                 /* ends the calling thread's parked helper threads */
 int hrt_launch_cache_enabled(uint64_t np);
 int hrt_launch_cache_get(uint64_t np, float *dirs, uint32_t *order);   /* copies; 1 if served */
 void hrt_launch_cache_put(uint64_t np, const float *dirs, const uint32_t *order);

@@ -3,7 +3,9 @@
     ASan + UBSan (tests/asan/), fed valid, truncated and corrupted .hrt / PLY / CSV / XML files and
     random triangle tables with NaNs, zero-area and duplicated triangles;
   * the oracle's C restatement under ASan + UBSan (make -C oracle asan), run from Python with the
-    sanitizer runtime preloaded, against a golden fixture.
+    sanitizer runtime preloaded, against a golden fixture;
+  * the parallel-for of the host writers (csrc/host/parallel.c: parked helper threads, one pool per
+    calling thread) under ThreadSanitizer and under ASan + UBSan.
 A sanitizer report ends the process with a status other than 0 (ok) or 8 (the loader's own
 "bad file" exit, the reference's code, src/scene.c:36-83)."""
 import os
@@ -117,3 +119,18 @@ def test_oracle_under_asan():
                ASAN_OPTIONS="detect_leaks=0:exitcode=99")
     q = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert q.returncode == 0 and "ORACLE_ASAN_OK" in q.stdout, q.stdout[-1000:] + q.stderr[-3000:]
+
+
+@pytest.mark.parametrize("target", ["parallel_tsan", "parallel_asan"])
+def test_parallel_for_of_the_host_writers(target):
+    """csrc/host/parallel.c (helper threads parked between loops, one pool per calling thread) under
+    ThreadSanitizer and under ASan + UBSan: many loops of changing size and thread count, release and
+    restart, four calling threads at once; every index of every loop visited exactly once."""
+    p = subprocess.run(["make", "-C", ASAN_DIR, target], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=1:exitcode=97")
+    r = subprocess.run([os.path.join(ASAN_DIR, target)], env=env, capture_output=True, text=True, timeout=600)
+    if target == "parallel_tsan" and r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow here (address-space layout of this kernel)")
+    assert r.returncode == 0 and "PARALLEL_OK" in r.stdout, r.stdout[-500:] + r.stderr[-3000:]
+    assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
