@@ -111,6 +111,7 @@ static void work_free(work_t *w)
     free(w->h_dirs); free(w->h_counts); free(w->h_los);
     /* D2H staging is page-locked (hipHostMalloc): 2-4x the pageable copy rate */
     hrt_hip_host_free(w->ray); hrt_hip_host_free(w->tri); hrt_hip_host_free(w->fs0);
+    hrt_hip_host_free(w->ray2); hrt_hip_host_free(w->tri2);
     for (int k = 0; k < 6; ++k) hrt_hip_host_free(w->st[k]);
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec[k]);
     hrt_hip_host_free(w->mask);
@@ -363,6 +364,8 @@ int hrt_worker_alloc(dev_ctx *c)
     int ok = w->h_order && w->h_counts && w->h_los && w->run_start && w->run_tx;
     ok &= hrt_hip_host_malloc((void **)&w->ray, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->tri, cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->ray2, cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->tri2, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->fs0, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask, cap / 64 * 8 + 8) == 0;
     for (int k = 0; k < 6 && with_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w->st[k], cap * 4) == 0;
@@ -384,7 +387,7 @@ void hrt_worker_release(dev_ctx *c)
     free(w->cur_rays); w->cur_rays = NULL;
     free(w->active); free(w->next_active); w->active = w->next_active = NULL;
     free(w->dirs_batch); w->dirs_batch = NULL;
-    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (2 + 2 * HRT_REC_FIELDS + 6);
+    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (4 + 2 * HRT_REC_FIELDS + 6);
     if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 6ull << 30)) {
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
         if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);
@@ -503,11 +506,24 @@ static int run_batch(dev_ctx *c, uint32_t g)
             }
     }
 
-    /* ---- bounces: scatter the compact blocks into the dense arrays ---- */
+    /* ---- bounces: scatter the compact blocks into the dense arrays ----
+     * With one TX (one run per bounce) the NEXT bounce is started while the last block of this one is
+     * written: its rays and triangles and its first record block are requested then (`pre`), so no
+     * copy is waited for with the writer idle except the very first. */
+    const int can_pre = (ntx == 1) && !scat_rays && !env_int("HRT_NO_BOUNCE_PREFETCH", 0);
+    int pre = 0, flip = 0;   /* staging set of a block: (slot + flip) & 1 */
     for (size_t b = 0; b < nb; ++b) {
         const uint64_t H = w->h_counts[b + 1];
         const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
-        if (H) {
+        const int prefetched = pre;
+        pre = 0;
+        if (H && prefetched) {   /* requested during the previous bounce, into the second pair of arrays */
+            uint32_t *t_ = w->ray; w->ray = w->ray2; w->ray2 = t_;
+            t_ = w->tri; w->tri = w->tri2; w->tri2 = t_;
+            int e = hrt_hip_stream_sync(w->copy_stream);
+            if (!e) e = hrt_hip_stream_sync(w->copy_stream2);
+            if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
+        } else if (H) {
             DL(w->ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
             DL(w->tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
             if (scat_rays)
@@ -523,16 +539,16 @@ static int run_batch(dev_ctx *c, uint32_t g)
          * compaction is stable), and per TX the adds go first, then that TX's records. */
         /* records of (b, rx): D2H into one of two page-locked staging sets on a copy stream,
          * so that the copy of block rx+1 runs while the host threads scatter block rx */
-#define FETCH_RX(RX, SET_REC, SET_MASK, I0, I1)                                                      \
+#define FETCH_RX(B, RX, SET_REC, SET_MASK, I0, I1)                                                   \
     do {                                                                                             \
-        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
+        const uint64_t rb_ = L.off_recs + (uint64_t)(B) * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
         const uint64_t i0_ = (I0), n_ = (I1) - (I0), w0_ = (I0) / 64, w1_ = ((I1) + 63) / 64;         \
         int e_ = 0;                                                                                  \
         for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
             e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w->d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, \
                                    (k & 1) ? w->copy_stream2 : w->copy_stream);                      \
         if (!e_)                                                                                     \
-            e_ = hrt_hip_d2h_async((SET_MASK) + w0_, (const uint8_t *)w->d_ws + L.off_masks + (((uint64_t)b * nrx + (RX)) * (L.cap / 64) + w0_) * 8, \
+            e_ = hrt_hip_d2h_async((SET_MASK) + w0_, (const uint8_t *)w->d_ws + L.off_masks + (((uint64_t)(B) * nrx + (RX)) * (L.cap / 64) + w0_) * 8, \
                                    (w1_ - w0_) * 8, w->copy_stream2);                                \
         if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
     } while (0)
@@ -567,9 +583,12 @@ static int run_batch(dev_ctx *c, uint32_t g)
                               prob->dop_mult, txr * n_loc, r0};
                 hrt_parallel_ranges(q10_range, &qc, r1 - r0, c->scatter_threads);
             }
-            if (run == 0) FETCH_RX(0, w->rec, w->mask, r0, r1);
+            if (run == 0 && !prefetched) {
+                if (flip & 1) FETCH_RX(b, 0, w->rec2, w->mask2, r0, r1);
+                else FETCH_RX(b, 0, w->rec, w->mask, r0, r1);
+            }
             for (size_t rx = 0; rx < nrx; ++rx) {
-                const size_t slot = (size_t)(run * nrx + rx);
+                const size_t slot = (size_t)(run * nrx + rx) + (size_t)flip;
                 float *const *cur_rec = (slot & 1) ? w->rec2 : w->rec;
                 const uint64_t *cur_mask = (slot & 1) ? w->mask2 : w->mask;
                 {
@@ -581,8 +600,18 @@ static int run_batch(dev_ctx *c, uint32_t g)
                     const size_t nrx_next = (rx + 1 < nrx) ? rx + 1 : 0;
                     const uint64_t n0_ = (rx + 1 < nrx) ? r0 : w->run_start[run + 1];
                     const uint64_t n1_ = (rx + 1 < nrx) ? r1 : w->run_start[run + 2];
-                    if (slot & 1) FETCH_RX(nrx_next, w->rec, w->mask, n0_, n1_);
-                    else FETCH_RX(nrx_next, w->rec2, w->mask2, n0_, n1_);
+                    if (slot & 1) FETCH_RX(b, nrx_next, w->rec, w->mask, n0_, n1_);
+                    else FETCH_RX(b, nrx_next, w->rec2, w->mask2, n0_, n1_);
+                } else if (can_pre && b + 1 < nb && w->h_counts[b + 2] != 0) {
+                    /* the last block of this bounce: the next bounce's rays, triangles and first block */
+                    const uint64_t Hn = w->h_counts[b + 2], hbn = L.off_hits + (b + 1) * L.hit_block_bytes;
+                    int e = hrt_hip_d2h_async(w->ray2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_RAY * L.cap * 4, Hn * 4, w->copy_stream);
+                    if (!e) e = hrt_hip_d2h_async(w->tri2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_TRI * L.cap * 4, Hn * 4, w->copy_stream2);
+                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e); goto done; }
+                    if (slot & 1) FETCH_RX(b + 1, 0, w->rec, w->mask, 0, Hn);
+                    else FETCH_RX(b + 1, 0, w->rec2, w->mask2, 0, Hn);
+                    pre = 1;
+                    flip = (int)((slot + 1) & 1);   /* slot 0 of the next bounce is the set just requested */
                 }
                 {
                     scatter_ctx sc;
