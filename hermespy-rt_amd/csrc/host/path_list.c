@@ -254,9 +254,13 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             const uint64_t H = h_counts[b + 1];
             if (!H) continue;
             const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
-            DLP(h_ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
-            DLP(h_tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
-            DLP(h_fs0, hb + (uint64_t)HRT_HIT_FS0 * L.cap * 4, H * 4);
+            {   /* per-hit data of this bounce: on the copy stream, in front of its first record block
+                 * (everything is waited for together before the first fill) */
+                int e_ = hrt_hip_d2h_async(h_ray, (const uint8_t *)d_ws + hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4, copy_stream);
+                if (!e_) e_ = hrt_hip_d2h_async(h_tri, (const uint8_t *)d_ws + hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4, copy_stream);
+                if (!e_) e_ = hrt_hip_d2h_async(h_fs0, (const uint8_t *)d_ws + hb + (uint64_t)HRT_HIT_FS0 * L.cap * 4, H * 4, copy_stream);
+                if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }
+            }
 #define FETCH_PL(RX, SET, MASK)                                                                   \
     do {                                                                                          \
         const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
