@@ -97,14 +97,16 @@ def test_compute_paths_list_matches_the_dense_result(rt):
     assert not both["a_te"][blk].any() and not both["tau"][blk].any()
 
 
-@pytest.mark.parametrize("name", ["C3_20k", "C4_DOPPLER_5k"])
-def test_complex_amplitudes_written_in_place(rt, product_lib, name):
+@pytest.mark.parametrize("name", ["C3_20k", "C4_DOPPLER_5k", "C3_20k_two_devices"])
+def test_complex_amplitudes_written_in_place(rt, product_lib, name, monkeypatch):
     """The module hands its complex64 arrays to hrt_compute_paths_interleaved (re at [2 i], im at
     [2 i + 1]); the reference's binding fills four planes and interleaves them
     (compute_paths_pybind11.cpp:44-97).  Same bits as the planes of hrt_compute_paths_ex, LoS
     block included; slots nobody writes read 0."""
     from hermespy_rt_amd import abi
-    c = K.small(K.C3, 20000) if name == "C3_20k" else K.small(K.C4_DOPPLER, 5000)
+    if name.endswith("two_devices"):
+        monkeypatch.setenv("HRT_DEVICES", "0,0")   # two logical devices write into the same complex arrays
+    c = K.small(K.C3, 20000) if name.startswith("C3_20k") else K.small(K.C4_DOPPLER, 5000)
     f32 = lambda a: np.array(a, np.float32)   # noqa: E731
     los, scat = rt.compute_paths(c["scene_path"], f32(c["rx_pos"]), f32(c["tx_pos"]), f32(c["rx_vel"]),
                                  f32(c["tx_vel"]), c["f_ghz"], len(c["rx_pos"]), len(c["tx_pos"]),
