@@ -136,7 +136,7 @@ def scene_to_numpy(scene):
 
 
 def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, num_paths,
-                      num_bounces, zero_freq_shift=None, with_rays=True, stats=None):
+                      num_bounces, zero_freq_shift=None, with_rays=True, stats=None, interleaved=False):
     """Call `lib.compute_paths` the way the reference's own callers do
     (compute_paths_pybind11.cpp:99-186, test/test.c:10-75) and return every output as numpy.
 
@@ -159,9 +159,22 @@ def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nu
                  a_te_re=_sentinel(n), a_te_im=_sentinel(n), a_tm_re=_sentinel(n),
                  a_tm_im=_sentinel(n), tau=_sentinel(n), freq_shift=_sentinel(n))
         ci = ChannelInfo()
+        if interleaved:
+            # hrt_compute_paths_interleaved: re and im of one polarisation share an array of 2 n floats
+            # (what a complex64 array is); the result dict still shows them as two (strided) planes
+            for pol in ("a_te", "a_tm"):
+                both = _sentinel(2 * n)
+                d[pol + "_both"] = both
+                d[pol + "_re"], d[pol + "_im"] = both[0::2], both[1::2]
         for k, v in d.items():
+            if k.endswith("_both"):
+                continue
             ptr_t = C.POINTER(Vec3) if k.startswith("directions") else c_float_p
-            setattr(ci, k, v.ctypes.data_as(ptr_t))
+            if interleaved and k in ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im"):
+                base = d[k[:4] + "_both"].ctypes.data + (4 if k.endswith("_im") else 0)
+                setattr(ci, k, C.cast(base, c_float_p))
+            else:
+                setattr(ci, k, v.ctypes.data_as(ptr_t))
         return d, ci
 
     n_los = nrx * ntx
@@ -188,9 +201,10 @@ def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nu
 
     scene = lib.scene_load(str(scene_path).encode())
     try:
-        if stats is not None or not with_rays:
-            # product-only entry point: status code, optional RaysInfo, counters
-            rc = lib.hrt_compute_paths_ex(C.byref(scene), rxp_c, txp_c, rxv_c, txv_c,
+        if stats is not None or not with_rays or interleaved:
+            # product-only entry points: status code, optional RaysInfo, counters
+            entry = lib.hrt_compute_paths_interleaved if interleaved else lib.hrt_compute_paths_ex
+            rc = entry(C.byref(scene), rxp_c, txp_c, rxv_c, txv_c,
                                           C.c_float(f_ghz), nrx, ntx, npth, nb, C.byref(los_c),
                                           C.byref(lr) if with_rays else None, C.byref(scat_c),
                                           C.byref(sr) if with_rays else None,
@@ -206,6 +220,8 @@ def run_compute_paths(lib, scene_path, rx_pos, tx_pos, rx_vel, tx_vel, f_ghz, nu
         free_scene(scene)
 
     shp = (nrx, ntx, nb, npth)
+    los = {k: v for k, v in los.items() if not k.endswith("_both")}
+    scat = {k: v for k, v in scat.items() if not k.endswith("_both")}
     res = dict(
         los={k: (v.reshape(nrx, ntx, 3) if k.startswith("directions") else v.reshape(nrx, ntx))
              for k, v in los.items()},
