@@ -111,7 +111,7 @@ static void work_free(work_t *w)
     free(w->h_dirs); free(w->h_counts); free(w->h_los);
     /* D2H staging is page-locked (hipHostMalloc): 2-4x the pageable copy rate */
     hrt_hip_host_free(w->ray); hrt_hip_host_free(w->tri); hrt_hip_host_free(w->fs0);
-    hrt_hip_host_free(w->ray2); hrt_hip_host_free(w->tri2);
+    hrt_hip_host_free(w->ray2); hrt_hip_host_free(w->tri2); hrt_hip_host_free(w->fs02);
     for (int k = 0; k < 6; ++k) hrt_hip_host_free(w->st[k]);
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec[k]);
     hrt_hip_host_free(w->mask);
@@ -367,6 +367,7 @@ int hrt_worker_alloc(dev_ctx *c)
     ok &= hrt_hip_host_malloc((void **)&w->tri, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->ray2, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->tri2, cap * 4) == 0;
+    ok &= hrt_hip_host_malloc((void **)&w->fs02, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->fs0, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask, cap / 64 * 8 + 8) == 0;
     for (int k = 0; k < 6 && with_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w->st[k], cap * 4) == 0;
@@ -388,7 +389,7 @@ void hrt_worker_release(dev_ctx *c)
     free(w->cur_rays); w->cur_rays = NULL;
     free(w->active); free(w->next_active); w->active = w->next_active = NULL;
     free(w->dirs_batch); w->dirs_batch = NULL;
-    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (4 + 2 * HRT_REC_FIELDS + 6);
+    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (5 + 2 * HRT_REC_FIELDS + 6);
     if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 24ull << 30)) {
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
         if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);

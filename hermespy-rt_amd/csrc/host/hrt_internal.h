@@ -99,7 +99,7 @@ typedef struct {
     float *h_los;
     uint32_t *ray, *tri;    /* per-bounce downloads */
     uint32_t *ray2, *tri2;  /* ... of the NEXT bounce, requested while the last block of this one is written */
-    float *fs0;             /* launch Doppler term of the hits (path-list writer) */
+    float *fs0, *fs02;      /* launch Doppler term of the hits (path-list writer), this bounce's and the next's */
     float *st[6];           /* o, d of the hits */
     float *rec[HRT_REC_FIELDS];
     uint64_t *mask;

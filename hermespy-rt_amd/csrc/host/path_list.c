@@ -147,11 +147,11 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     memset(&wc, 0, sizeof wc);
     int pool_taken = 0, have_buffers = 0;
     void *d_ws = NULL, *d_dirs = NULL, *d_order = NULL;
-    float *h_dirs = NULL, **h_field = NULL, **h_field2 = NULL, *h_fs0 = NULL;
+    float *h_dirs = NULL, **h_field = NULL, **h_field2 = NULL, *h_fs0 = NULL, *h_fs02 = NULL;
     uint64_t *h_mask = NULL, *h_mask2 = NULL;
     void *copy_stream = NULL;
     const int host_launch = (int)pl_env_u64("HRT_HOST_LAUNCH", 0);
-    uint32_t *h_order = NULL, *h_ray = NULL, *h_tri = NULL, *h_counts = NULL;
+    uint32_t *h_order = NULL, *h_ray = NULL, *h_tri = NULL, *h_ray2 = NULL, *h_tri2 = NULL, *h_counts = NULL;
     uint64_t cap_out = 0;
     const int threads = hrt_host_threads();
     double t_dev = 0.0, t_rb = 0.0, t_dirs = 0.0;
@@ -187,6 +187,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         d_ws = wc.w.d_ws; d_dirs = wc.w.d_dirs; d_order = wc.w.d_order;
         h_order = wc.w.h_order; h_counts = wc.w.h_counts;
         h_ray = wc.w.ray; h_tri = wc.w.tri; h_fs0 = wc.w.fs0;
+        h_ray2 = wc.w.ray2; h_tri2 = wc.w.tri2; h_fs02 = wc.w.fs02;
         h_field = wc.w.rec; h_field2 = wc.w.rec2; h_mask = wc.w.mask; h_mask2 = wc.w.mask2;
         copy_stream = wc.w.copy_stream;
         if (host_launch) {
@@ -250,38 +251,61 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             for (size_t b = 0; b < nb; ++b) recs += (uint64_t)nrx * h_counts[b + 1];
             if ((rc = pl_reserve(out, &cap_out, out->num + recs))) goto done;
         }
+        int pre = 0, flip = 0;   /* staging set of a block: (rx + flip) & 1 */
+        const int can_pre = !(int)pl_env_u64("HRT_NO_BOUNCE_PREFETCH", 0);
         for (size_t b = 0; b < nb; ++b) {
             const uint64_t H = h_counts[b + 1];
             if (!H) continue;
-            const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
-            {   /* per-hit data of this bounce: on the copy stream, in front of its first record block
-                 * (everything is waited for together before the first fill) */
-                int e_ = hrt_hip_d2h_async(h_ray, (const uint8_t *)d_ws + hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4, copy_stream);
-                if (!e_) e_ = hrt_hip_d2h_async(h_tri, (const uint8_t *)d_ws + hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4, copy_stream);
-                if (!e_) e_ = hrt_hip_d2h_async(h_fs0, (const uint8_t *)d_ws + hb + (uint64_t)HRT_HIT_FS0 * L.cap * 4, H * 4, copy_stream);
-                if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }
-            }
-#define FETCH_PL(RX, SET, MASK)                                                                   \
+            /* Per-hit data (ray, triangle, launch Doppler term) and record blocks go out on the copy
+             * stream, a block ahead of the one being written into the list; the NEXT bounce's per-hit data
+             * and first block are requested during the last block of this one (`pre`), into the second
+             * pair of arrays / the other staging set. */
+#define FETCH_HITS(B, HN, RAY, TRI, FS0)                                                          \
     do {                                                                                          \
-        const uint64_t rb_ = L.off_recs + b * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
-        int e_ = 0;                                                                               \
-        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                           \
-            e_ = hrt_hip_d2h_async((SET)[k], (const uint8_t *)d_ws + rb_ + (uint64_t)k * L.cap * 4, H * 4, copy_stream); \
-        if (!e_) e_ = hrt_hip_d2h_async((MASK), (const uint8_t *)d_ws + L.off_masks + ((uint64_t)b * nrx + (RX)) * (L.cap / 64) * 8, \
-                                        (H + 63) / 64 * 8, copy_stream);                          \
+        const uint64_t hb_ = L.off_hits + (uint64_t)(B) * L.hit_block_bytes;                      \
+        int e_ = hrt_hip_d2h_async((RAY), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_RAY * L.cap * 4, (HN) * 4, copy_stream); \
+        if (!e_) e_ = hrt_hip_d2h_async((TRI), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_TRI * L.cap * 4, (HN) * 4, copy_stream); \
+        if (!e_) e_ = hrt_hip_d2h_async((FS0), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_FS0 * L.cap * 4, (HN) * 4, copy_stream); \
         if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }    \
     } while (0)
-            FETCH_PL(0, h_field, h_mask);
+#define FETCH_PL(B, HN, RX, SET, MASK)                                                            \
+    do {                                                                                          \
+        const uint64_t rb_ = L.off_recs + (uint64_t)(B) * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
+        int e_ = 0;                                                                               \
+        for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                           \
+            e_ = hrt_hip_d2h_async((SET)[k], (const uint8_t *)d_ws + rb_ + (uint64_t)k * L.cap * 4, (HN) * 4, copy_stream); \
+        if (!e_) e_ = hrt_hip_d2h_async((MASK), (const uint8_t *)d_ws + L.off_masks + ((uint64_t)(B) * nrx + (RX)) * (L.cap / 64) * 8, \
+                                        ((HN) + 63) / 64 * 8, copy_stream);                       \
+        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }    \
+    } while (0)
+            if (pre) {   /* requested during the previous bounce */
+                uint32_t *t_ = h_ray; h_ray = h_ray2; h_ray2 = t_;
+                t_ = h_tri; h_tri = h_tri2; h_tri2 = t_;
+                float *f_ = h_fs0; h_fs0 = h_fs02; h_fs02 = f_;
+                pre = 0;
+            } else {
+                FETCH_HITS(b, H, h_ray, h_tri, h_fs0);
+                if (flip & 1) FETCH_PL(b, H, 0, h_field2, h_mask2);
+                else FETCH_PL(b, H, 0, h_field, h_mask);
+            }
             for (size_t rx = 0; rx < nrx; ++rx) {
-                float *const *cur_field = (rx & 1) ? h_field2 : h_field;
-                const uint64_t *cur_mask = (rx & 1) ? h_mask2 : h_mask;
+                const size_t slot = rx + (size_t)flip;
+                float *const *cur_field = (slot & 1) ? h_field2 : h_field;
+                const uint64_t *cur_mask = (slot & 1) ? h_mask2 : h_mask;
                 {
                     const int e = hrt_hip_stream_sync(copy_stream);   /* block rx has landed */
                     if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
                 }
                 if (rx + 1 < nrx) {   /* the copy of the next block runs while this one is written out */
-                    if (rx & 1) FETCH_PL(rx + 1, h_field, h_mask);
-                    else FETCH_PL(rx + 1, h_field2, h_mask2);
+                    if (slot & 1) FETCH_PL(b, H, rx + 1, h_field, h_mask);
+                    else FETCH_PL(b, H, rx + 1, h_field2, h_mask2);
+                } else if (can_pre && b + 1 < nb && h_counts[b + 2] != 0) {   /* ... or the start of the next bounce */
+                    const uint64_t Hn = h_counts[b + 2];
+                    FETCH_HITS(b + 1, Hn, h_ray2, h_tri2, h_fs02);
+                    if (slot & 1) FETCH_PL(b + 1, Hn, 0, h_field, h_mask);
+                    else FETCH_PL(b + 1, Hn, 0, h_field2, h_mask2);
+                    pre = 1;
+                    flip = (int)((slot + 1) & 1);
                 }
                 {
                     fill_ctx fc;
@@ -311,6 +335,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         t_rb += hrt_now_s() - t0;
     }
 #undef FETCH_PL
+#undef FETCH_HITS
 #undef DLP
     st.t_launch_dirs_s = t_dirs;
     st.t_device_s = t_dev;
