@@ -97,3 +97,27 @@ def test_many_calls_reuse_the_parked_helper_threads(product_lib):
             os.environ.pop("HRT_HOST_THREADS", None)
         else:
             os.environ["HRT_HOST_THREADS"] = old
+
+
+def test_several_batches_on_one_device(product_lib, monkeypatch):
+    """A workspace budget that the launch set does not fit (HRT_WORKSPACE_BYTES): ONE worker runs
+    several round-robin batches one after the other through the same buffers -- dense and list -- and
+    the result is still the oracle's, bit for bit."""
+    from hermespy_rt_amd import abi, lib
+    from oracle import oracle
+    from . import configs as K
+    from .parity import compare_dense
+    monkeypatch.setenv("HRT_WORKSPACE_BYTES", str(40 << 20))
+    for c in (K.small(K.C3, 150000), K.small(K.C4_DOPPLER, 60001)):
+        st = lib.Stats()
+        got = abi.run_compute_paths(product_lib, *K.args(c), with_rays=False, stats=st)
+        ref = oracle.compute_paths(*K.args(c))
+        for k in ("los_rays", "los_active", "scat_rays", "scat_active"):
+            ref[k] = got[k]
+        s = compare_dense(got, ref)
+        assert all(v == 0 for v in s.values()), s
+        assert st.num_batches > 1 and st.num_devices == 1, (st.num_batches, st.num_devices)
+        pl = abi.run_compute_paths_list(product_lib, *K.args(c))
+        w = abi.written(ref["scat"]["directions_rx"][..., 0])
+        assert pl["rx"].size == int(w.sum())
+    product_lib.hrt_cache_clear()
