@@ -366,7 +366,7 @@ def main():
         from hermespy_rt_amd import lib as _l2
         arr = (ctypes.c_uint64 * 48)()
         if _l2.load().hrt_debug_kernel_stats(local_rank, arr, 0) == 0 and any(arr):
-            kstats = [[int(arr[k * 16 + j]) for j in range(8)] for k in range(3)]
+            kstats = [[int(arr[k * 16 + j]) for j in range(16)] for k in range(3)]
     except Exception:
         pass
     out = None

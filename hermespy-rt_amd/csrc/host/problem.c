@@ -91,6 +91,54 @@ static void rxt_dir(uint32_t f, double u, double v, double out[3])
     out[0] = c[0] / l; out[1] = c[1] / l; out[2] = c[2] / l;
 }
 
+/* cones of the 6 x 48 x 48 cube-map cells (axis as the device gets it, cos / sin of the half-angle),
+ * widened by `aq` (the widest packet served; 0 for per-ray lookups) and by the rounding of the
+ * device's cell lookup.  A pure function of aq: computed once per process for each of the two
+ * values in use. */
+static pthread_mutex_t g_bins_lock = PTHREAD_MUTEX_INITIALIZER;
+static float *g_bins[2];   /* [0] aq = asin(HRT_RXT_SIN_AQ), [1] aq = 0: NB * 6 floats (dir4, cs2) */
+static const float *rxt_bins(int per_ray)
+{
+    pthread_mutex_lock(&g_bins_lock);
+    float *b = g_bins[per_ray];
+    if (!b) {
+        const uint32_t NB = HRT_RXT_BINS;
+        b = (float *)malloc((size_t)NB * 6 * sizeof(float));
+        if (b) {
+            float *bin_dir = b, *bin_cs = b + (size_t)NB * 4;
+            const double aq = per_ray ? 0.0 : asin((double)HRT_RXT_SIN_AQ);
+            for (uint32_t f = 0; f < 6; ++f)
+                for (uint32_t iv = 0; iv < HRT_RXT_N; ++iv)
+                    for (uint32_t iu = 0; iu < HRT_RXT_N; ++iu) {
+                        const uint32_t cell = (f * HRT_RXT_N + iv) * HRT_RXT_N + iu;
+                        const double u0 = 2.0 * iu / HRT_RXT_N - 1.0, u1 = 2.0 * (iu + 1) / HRT_RXT_N - 1.0;
+                        const double v0 = 2.0 * iv / HRT_RXT_N - 1.0, v1 = 2.0 * (iv + 1) / HRT_RXT_N - 1.0;
+                        double ctr[3], q[3], cmin = 1.0;
+                        rxt_dir(f, 0.5 * (u0 + u1), 0.5 * (v0 + v1), ctr);
+                        const float cfl[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};   /* what the device gets */
+                        const double fl = sqrt((double)cfl[0] * cfl[0] + (double)cfl[1] * cfl[1] + (double)cfl[2] * cfl[2]);
+                        const double us[2] = {u0, u1}, vs[2] = {v0, v1};
+                        for (int a = 0; a < 2; ++a)
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                rxt_dir(f, us[a], vs[c2], q);
+                                const double cc = (q[0] * cfl[0] + q[1] * cfl[1] + q[2] * cfl[2]) / fl;
+                                if (cc < cmin) cmin = cc;
+                            }
+                        /* cone of the cell + the widest packet served + rounding of the cell lookup */
+                        const double ang = acos(cmin > 1 ? 1 : cmin) + aq + 3e-4;
+                        bin_dir[4 * cell] = cfl[0]; bin_dir[4 * cell + 1] = cfl[1]; bin_dir[4 * cell + 2] = cfl[2]; bin_dir[4 * cell + 3] = 0.f;
+                        float cs = (float)cos(ang), sn = (float)sin(ang);
+                        if ((double)cs > cos(ang)) cs = nextafterf(cs, -1.f);      /* wider, never narrower */
+                        if ((double)sn < sin(ang)) sn = nextafterf(sn, 2.f);
+                        bin_cs[2 * cell] = cs; bin_cs[2 * cell + 1] = sn;
+                    }
+            g_bins[per_ray] = b;
+        }
+    }
+    pthread_mutex_unlock(&g_bins_lock);
+    return b;
+}
+
 static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
 {
     /* apexes: the RXs (shadow rays converge on them), then the TXs (the launch set leaves them) */
@@ -98,9 +146,14 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
     const char *off_env = getenv("HRT_NO_RXT"), *notx_env = getenv("HRT_NO_TXT");
     uint32_t max_tri = HRT_RXT_MAX_TRI;
     { const char *mv = getenv("HRT_RXT_MAX_TRI"); if (mv && *mv) max_tri = (uint32_t)atol(mv); if (max_tri > 65535u) max_tri = 65535u; }
-    /* (up to 64 triangles the whole table is ONE culling round: a list cannot be cheaper) */
-    if (T <= 64 || T > max_tri || n_rx > 64 || (off_env && *off_env && *off_env != '0')) return HRT_OK;
-    const uint32_t n_txt = (n_rx + p->num_tx <= 64 && !(notx_env && *notx_env && *notx_env != '0')) ? p->num_tx : 0u;
+    /* Up to 64 triangles the whole table is ONE culling round, a list cannot be cheaper: there the
+     * tables are one 64-bit candidate MASK per (apex, cell), built for the cell alone, looked up per
+     * ray (closest_hit_masked) -- RXs and TXs alike, up to 256 apexes (110 KB each). */
+    const int per_ray = T <= 64;
+    if (T > max_tri || (off_env && *off_env && *off_env != '0')) return HRT_OK;
+    if (per_ray ? (n_rx + p->num_tx > 256) : (n_rx > 64)) return HRT_OK;
+    const uint32_t n_txt = per_ray ? p->num_tx
+                                   : ((n_rx + p->num_tx <= 64 && !(notx_env && *notx_env && *notx_env != '0')) ? p->num_tx : 0u);
     const uint32_t nrx = n_rx + n_txt;
     /* the ball every ray origin lies in: hit points are on triangles (+ 1e-4 along the new direction) */
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -129,42 +182,17 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
     if (!isfinite(region_r)) return HRT_OK;
 
     const uint32_t NB = HRT_RXT_BINS, W = (T + 63u) / 64u;
-    float *bin_dir = (float *)malloc((size_t)NB * 4 * sizeof(float));
-    float *bin_cs = (float *)malloc((size_t)NB * 2 * sizeof(float));
+    const float *bins = rxt_bins(per_ray);
+    if (!bins) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    const float *bin_dir = bins, *bin_cs = bins + (size_t)NB * 4;
     float *ro_bin = (float *)malloc((size_t)nrx * sizeof(float));
     float *apex = (float *)malloc((size_t)nrx * 3 * sizeof(float));
-    uint64_t *masks = (uint64_t *)malloc((size_t)nrx * NB * W * 8);
-    uint32_t *off = (uint32_t *)malloc(((size_t)nrx * NB + 1) * 4);
+    uint64_t *masks = per_ray ? NULL : (uint64_t *)malloc((size_t)nrx * NB * W * 8);
+    uint32_t *off = per_ray ? NULL : (uint32_t *)malloc(((size_t)nrx * NB + 1) * 4);
     int rc = HRT_OK, e;
     void *d_tmp = NULL;
     uint16_t *idx = NULL;
-    if (!bin_dir || !bin_cs || !ro_bin || !apex || !masks || !off) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
-    const double aq = asin((double)HRT_RXT_SIN_AQ);
-    for (uint32_t f = 0; f < 6; ++f)
-        for (uint32_t iv = 0; iv < HRT_RXT_N; ++iv)
-            for (uint32_t iu = 0; iu < HRT_RXT_N; ++iu) {
-                const uint32_t cell = (f * HRT_RXT_N + iv) * HRT_RXT_N + iu;
-                const double u0 = 2.0 * iu / HRT_RXT_N - 1.0, u1 = 2.0 * (iu + 1) / HRT_RXT_N - 1.0;
-                const double v0 = 2.0 * iv / HRT_RXT_N - 1.0, v1 = 2.0 * (iv + 1) / HRT_RXT_N - 1.0;
-                double ctr[3], q[3], cmin = 1.0;
-                rxt_dir(f, 0.5 * (u0 + u1), 0.5 * (v0 + v1), ctr);
-                const float cfl[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};   /* what the device gets */
-                const double fl = sqrt((double)cfl[0] * cfl[0] + (double)cfl[1] * cfl[1] + (double)cfl[2] * cfl[2]);
-                const double us[2] = {u0, u1}, vs[2] = {v0, v1};
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b) {
-                        rxt_dir(f, us[a], vs[b], q);
-                        const double cc = (q[0] * cfl[0] + q[1] * cfl[1] + q[2] * cfl[2]) / fl;
-                        if (cc < cmin) cmin = cc;
-                    }
-                /* cone of the cell + the widest packet served + rounding of the cell lookup */
-                const double ang = acos(cmin > 1 ? 1 : cmin) + aq + 3e-4;
-                bin_dir[4 * cell] = cfl[0]; bin_dir[4 * cell + 1] = cfl[1]; bin_dir[4 * cell + 2] = cfl[2]; bin_dir[4 * cell + 3] = 0.f;
-                float cs = (float)cos(ang), sn = (float)sin(ang);
-                if ((double)cs > cos(ang)) cs = nextafterf(cs, -1.f);      /* wider, never narrower */
-                if ((double)sn < sin(ang)) sn = nextafterf(sn, 2.f);
-                bin_cs[2 * cell] = cs; bin_cs[2 * cell + 1] = sn;
-            }
+    if (!ro_bin || !apex || (!per_ray && (!masks || !off))) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
     for (uint32_t r = 0; r < nrx; ++r) {
         const Vec3 a = r < n_rx ? rx_pos[r] : tx_pos[r - n_rx];
         apex[3 * r] = a.x; apex[3 * r + 1] = a.y; apex[3 * r + 2] = a.z;
@@ -179,7 +207,7 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
     {
         const uint64_t b_dir = (uint64_t)NB * 16, b_cs = (uint64_t)NB * 8, b_ro = (uint64_t)nrx * 4 + 252;
         const uint64_t b_mask = (uint64_t)nrx * NB * W * 8, b_apex = round_up((uint64_t)nrx * 12, 256);
-        if ((e = hrt_hip_malloc(&d_tmp, b_dir + b_cs + (b_ro & ~255ull) + 256 + b_apex + b_mask))) { rc = hrt_fail_hip(e, "hipMalloc(rxt build)"); goto out; }
+        if ((e = hrt_hip_malloc(&d_tmp, b_dir + b_cs + (b_ro & ~255ull) + 256 + b_apex + (per_ray ? 0 : b_mask)))) { rc = hrt_fail_hip(e, "hipMalloc(rxt build)"); goto out; }
         uint8_t *q = (uint8_t *)d_tmp;
         float *d_dir = (float *)q; q += b_dir;
         float *d_cs = (float *)q; q += b_cs;
@@ -189,9 +217,20 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
         if ((e = hrt_hip_h2d(d_dir, bin_dir, b_dir)) || (e = hrt_hip_h2d(d_cs, bin_cs, b_cs)) ||
             (e = hrt_hip_h2d(d_ro, ro_bin, (uint64_t)nrx * 4)) ||
             (e = hrt_hip_h2d(d_apex, apex, (uint64_t)nrx * 12))) { rc = hrt_fail_hip(e, "hipMemcpy(rxt build)"); goto out; }
+        if (per_ray) {
+            /* the masks ARE the table: built straight into the problem's own allocation */
+            if ((e = hrt_hip_malloc(&p->d_rxt, b_mask))) { p->d_rxt = NULL; rc = hrt_fail_hip(e, "hipMalloc(rxt)"); goto out; }
+            d_masks = (unsigned long long *)p->d_rxt;
+        }
         if ((e = hrt_hip_rxt_build(p->d_tri, T, d_apex, nrx, d_dir, d_cs, d_ro, cf[0], cf[1], cf[2], region_r,
                                    d_masks, NULL))) { rc = hrt_fail_hip(e, "hrt_rxt_build_kernel"); goto out; }
         if ((e = hrt_hip_stream_sync(NULL))) { rc = hrt_fail_hip(e, "hipStreamSynchronize"); goto out; }
+        if (per_ray) {
+            p->krxt.cell_mask = d_masks;
+            p->krxt.num_txt = n_txt;
+            p->krxt.cx = cf[0]; p->krxt.cy = cf[1]; p->krxt.cz = cf[2]; p->krxt.region_r = region_r;
+            goto out;
+        }
         if ((e = hrt_hip_d2h(masks, d_masks, b_mask))) { rc = hrt_fail_hip(e, "hipMemcpy D2H"); goto out; }
     }
     {
@@ -229,7 +268,8 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
     }
 out:
     if (d_tmp) hrt_hip_free(d_tmp);
-    free(bin_dir); free(bin_cs); free(ro_bin); free(apex); free(masks); free(off); free(idx);
+    free(ro_bin); free(apex); free(masks); free(off); free(idx);
+    if (rc && p->d_rxt) { hrt_hip_free(p->d_rxt); p->d_rxt = NULL; p->krxt.cell_mask = NULL; }
     return rc;
 }
 
@@ -468,7 +508,8 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         if (24u + txb > 32u) p->sort_rays = 0;   /* 15 bits of cell + up to 9 of direction + TX */
     }
     {
-        uint64_t min_rays = 1ull << 26;
+        /* (the per-ray masks of tables of <= 64 triangles need no host pass over the lists: ~0.2 ms) */
+        uint64_t min_rays = p->num_tri <= 64u ? 1ull << 18 : 1ull << 26;
         { const char *mv = getenv("HRT_RXT_MIN_RAYS"); if (mv && *mv) min_rays = strtoull(mv, NULL, 10); }
         if (rays_hint >= min_rays) {
             const int rcx = rxt_build(p, rx_pos, tx_pos);
@@ -804,6 +845,12 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
      * the counts, zeroed with them at the start of every trace */
     L->num_super = cap / HRT_BLOCK / HRT_SUPER_CHUNKS + 1;
     L->off_super_cnt = off; off += round_up(nb * L->num_super * 4, 256);
+    /* status words of the fused kernels' chained scan, one per chunk and launch: zeroed with the counts */
+    {
+        const uint64_t lbc = round_up(cap / HRT_BLOCK + 1, 64);
+        L->lb_stride = lbc + lbc / 64 + 128;   /* u32 words: per chunk, per group of 64, per supergroup of 4096 */
+    }
+    L->off_lb = off;     off += round_up((nb + 1) * L->lb_stride * 4, 256);
     L->off_los = off;    off += round_up((uint64_t)p->num_rx * p->num_tx * HRT_LOS_FLOATS * 4, 256);
     L->off_hits = off;   L->hit_block_bytes = (uint64_t)HRT_HIT_FIELDS * cap * 4; off += nb * L->hit_block_bytes;
     L->off_recs = off;   L->rec_block_bytes = (uint64_t)p->num_rx * HRT_REC_FIELDS * cap * 4; off += nb * L->rec_block_bytes;
@@ -909,6 +956,23 @@ int hrt_trace_flags(const hrt_problem *p, const hrt_shard *s, const float *d_dir
     return trace_impl(p, s, d_dirs, d_order, d_ws, ws_bytes, stream, timer, flags);
 }
 
+/* Which launches run as one fused kernel.  HRT_FUSE: unset = launch 0 on every table, whole bounces
+ * on tables of at most HRT_FUSE_MAX_TRI triangles (one culling round: there the split into a
+ * geometry kernel and a shading kernel only costs traffic and launches); 0 = never (two kernels per
+ * launch); 1 = launch 0 only; 2 = every launch, on any table of one culling block (<= 1024). */
+static uint32_t fuse_mode(const hrt_problem *p)
+{
+    const char *v = getenv("HRT_FUSE");
+    const int one_block = p->num_tri <= 1024u;
+    if (v && *v) {
+        const int m = atoi(v);
+        if (m <= 0) return 0u;
+        if (m == 1 || !one_block) return HRT_FUSE_LAUNCH0;
+        return HRT_FUSE_LAUNCH0 | HRT_FUSE_BOUNCES;
+    }
+    return HRT_FUSE_LAUNCH0 | (p->num_tri <= HRT_FUSE_MAX_TRI ? HRT_FUSE_BOUNCES : 0u);
+}
+
 static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_dirs,
                       const uint32_t *d_order, void *d_ws, uint64_t ws_bytes, void *stream,
                       hrt_timer *timer, uint32_t flags)
@@ -946,6 +1010,10 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.off_chunk_cnt = L.off_chunk_cnt; K.off_super_cnt = L.off_super_cnt;
     K.num_super = (uint32_t)L.num_super;
     K.off_res = L.off_res;
+    K.off_lb = L.off_lb;
+    K.lb_stride = (uint32_t)L.lb_stride;
+    K.lb_chunks = (uint32_t)round_up(L.cap / HRT_BLOCK + 1, 64);
+    K.fuse = fuse_mode(p);
     if (p->sort_rays) {
         uint32_t txb = 0;
         while ((1u << txb) < p->num_tx) ++txb;
@@ -1004,13 +1072,28 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     int hip = 0;
 #define STEP(call) do { if (!hip) hip = (call); } while (0)
     /* counts, device error flag, and the super-chunk counts right behind them */
-    STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0,
-                              L.off_super_cnt - L.off_counts + (uint64_t)nb * L.num_super * 4, stream));
+    STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0, L.off_los - L.off_counts, stream));
+    /* the LoS pass: its own (tiny) kernel, or -- when launch 0 is one fused kernel -- a few extra
+     * workgroups of that kernel (a launch less: it matters on launch sets of a few 10^4 rays) */
+    K.los_blocks = (K.fuse & HRT_FUSE_LAUNCH0) ? 1u : 0u;
     if (ev) STEP(hrt_hip_event_record(ev[0], stream));
-    STEP(hrt_hip_launch_los(&K, stream));
+    if (!K.los_blocks) STEP(hrt_hip_launch_los(&K, stream));
     if (ev) STEP(hrt_hip_event_record(ev[1], stream));
     for (uint32_t b = 0; b <= nb; ++b) {
         if (ev) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
+        /* one kernel for the whole launch (trace + shading + stable compaction) where that is what the
+         * launch wants: launch 0 always, every launch on tables of one culling round; then the
+         * "trace" time is the fused kernel's and the "shade" time zero */
+        const int fused = b == 0 ? (K.fuse & HRT_FUSE_LAUNCH0) != 0 : (K.fuse & HRT_FUSE_BOUNCES) != 0;
+        int fused_rc = -1;
+        if (fused && !hip) fused_rc = hrt_hip_launch_fused(&K, b, stream);   /* -1: this table / variant is not fusable */
+        if (fused_rc >= 0) {
+            STEP(fused_rc);
+            if (ev) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
+            if (p->sort_rays && b < nb) STEP(hrt_hip_sort_hits(&K, b, stream));
+            if (ev) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
+            continue;
+        }
         STEP(hrt_hip_launch_trace(&K, b, stream));
         if (ev) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));
         STEP(hrt_hip_launch_shade(&K, b, stream));

@@ -232,8 +232,13 @@ __device__ __forceinline__ Hit closest_hit_staged(TriPtr tri, const uint32_t *__
 // Diagnostic counters (built only with -DHRT_KERNEL_STATS, `make STATS=1`): per kind of trace
 // (0 primary of launch 0, 1 primary of later launches, 2 shadow): wave-traces, usable packets,
 // candidate triangles, staged bodies that reached stage 2 / 3 / the exact divisions.
-#ifdef HRT_KERNEL_STATS
+#if defined(HRT_KERNEL_STATS) || defined(HRT_PHASE_STATS)
 __device__ unsigned long long g_stats[3][HRT_STATS_COLS];
+#endif
+#ifdef HRT_PHASE_STATS
+__device__ unsigned long long g_phase[65536][8];
+#endif
+#ifdef HRT_KERNEL_STATS
 #define HRT_STAT(kind, idx, val)                                                      \
     do {                                                                              \
         if (lane == 0) atomicAdd(&g_stats[kind][idx], (unsigned long long)(val));     \
@@ -369,6 +374,36 @@ __device__ __forceinline__ float wave_min_f(float v)
         "s_nop 1\n"
         : "+v"(v));
     return lane63(v);
+}
+
+// bitwise OR of a 64-bit value over the wave (two interleaved 32-bit chains), wave-uniform result
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    asm volatile(
+        "s_nop 4\n"
+        "v_or_b32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "v_or_b32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_or_b32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "v_or_b32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_or_b32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_or_b32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_or_b32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_or_b32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_or_b32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "v_or_b32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_or_b32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "v_or_b32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(lo), "+v"(hi));
+    const uint32_t ulo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+    const uint32_t uhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)uhi << 32) | (unsigned long long)ulo;
 }
 
 struct Ball { F3 c; float r; bool ok; };   // bounding ball of the packet's ray origins
@@ -620,6 +655,44 @@ __device__ __forceinline__ uint32_t rxt_cell(F3 a)
     return (f * HRT_RXT_N + (uint32_t)iv) * HRT_RXT_N + (uint32_t)iu;
 }
 
+// Tables of at most 64 triangles, traces bound to an APEX (launch rays leave a TX, shadow rays
+// arrive at an RX): every lane looks up the candidate mask of the cube-map cell of ITS OWN direction
+// in the apex's table (hrt_krxt.cell_mask: what the packet test cannot reject for any line through
+// the apex with a direction in the cell, origins anywhere in the scene's ball -- built by the very
+// same packet_culls, hrt_rxt_build_kernel, so its soundness is that of the packet test on a bigger
+// packet), the wave ORs the masks, and the union is walked through the staged test.  No origin
+// ball, no cone, no culling round: ~60 instead of ~330 instructions in front of the walk.
+// `apex_k` is per lane (a wave of the launch set may straddle two TXs).  A lane whose origin is not
+// inside the ball the tables were built for (cannot happen for hit points and TXs; NaNs) asks for
+// every triangle.
+template <typename TriPtr>
+__device__ __forceinline__ Hit closest_hit_masked(TriPtr tri, const uint32_t *__restrict__ orig, const hrt_krxt &X,
+                                                  uint32_t apex_k, uint32_t num_tri, F3 o, F3 d, bool valid,
+                                                  uint32_t lane, [[maybe_unused]] int kind)
+{
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
+    const unsigned long long inval = HRT_BALLOT(!valid);
+    if (inval == ~0ull) return {who, best};
+    unsigned long long mine = 0ull;
+    if (valid) {
+        const F3 dc = sub3(o, {X.cx, X.cy, X.cz});
+        const bool inside = fast_sqrt(fdot3(dc, dc)) * 1.0001f <= X.region_r;   // NaN: false
+        mine = inside ? X.cell_mask[(uint64_t)apex_k * HRT_RXT_BINS + rxt_cell(d)]
+                      : (num_tri >= 64u ? ~0ull : ((1ull << num_tri) - 1ull));
+    }
+    unsigned long long m = wave_or64(mine);
+    HRT_STAT(kind, 0, 1);
+    HRT_STAT(kind, 1, 1);
+    HRT_STAT(kind, 2, __popcll(m));
+    while (m) {   // any order: ties go by (distance, original index)
+        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        HRT_STAGED_BODY(j)
+    }
+    return {who, best};
+}
+
 template <bool MULTI, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__restrict__ orig,
                                                   const hrt_krxt &X, uint32_t rxk,
@@ -687,14 +760,18 @@ __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__
         for (uint32_t base = blk0, r = 0; base < blk1; base += 64u, ++r) {
             // written by this wave's lane 0 above, read back by all its lanes: same wave, in order
             unsigned long long m = wmask[r];
+            // the rows of this round's items, one per lane: a candidate's row is then a v_readlane
+            // away instead of a dependent load of list[item] in front of every staged test
+            const uint32_t jl = base + lane;
+            const uint32_t rowv = (list && jl < blk1) ? (uint32_t)list[jl] : jl;
             // (the builtin returns int: widen through uint32_t or the low word sign-extends)
             const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
             const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
             m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
             while (m) {   // any order: ties go by (distance, original index)
-                const uint32_t it = base + (uint32_t)__builtin_ctzll(m);
+                const uint32_t bit = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1ull;
-                const uint32_t j = list ? (uint32_t)list[it] : it;   // `it` is wave-uniform: a scalar load
+                const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)rowv, (int)bit);
                 HRT_STAGED_BODY(j)
             }
         }
@@ -1425,10 +1502,11 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
         const bool valid = i < n_in;
         const bool shadow = k < P.num_rx;
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
+        uint32_t tx_lane = 0u;
         if (valid) {
             if (first) {
-                uint32_t ray, tx;
-                launch_ray(P, i, ray, o, d, tx);
+                uint32_t ray;
+                launch_ray(P, i, ray, o, d, tx_lane);
             } else {
                 const uint32_t pb = b - 1;
                 o = {ldf(hit_blk(P, pb), H_OX * cap4, i4), ldf(hit_blk(P, pb), H_OY * cap4, i4),
@@ -1455,13 +1533,18 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
             apex = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
             apex_k = P.num_rx + tx;
         }
+        // (tables of <= 64 triangles: apex-bound traces go through the per-cell candidate masks)
+        const bool masked = VARIANT == 2 && P.rxt.cell_mask != nullptr && (shadow || first);
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
-        if constexpr (VARIANT >= 2 && VARIANT != 6) ball = origin_ball(o, valid);
+        if constexpr (VARIANT >= 2 && VARIANT != 6)
+            if (!masked) ball = origin_ball(o, valid);
 #ifdef HRT_KERNEL_STATS
         const long long t_unit0 = clock64();
 #endif
-        const Hit h = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane, ball, shadow,
-                                           apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
+        const Hit h = masked ? closest_hit_masked(tri, P.acc.orig, P.rxt, shadow ? k : P.num_rx + tx_lane, T, o, d, valid,
+                                                  lane, shadow ? 2 : 0)
+                             : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane,
+                                                    ball, shadow, apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
 #ifdef HRT_KERNEL_STATS
         if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks
             const unsigned long long dt = (unsigned long long)(clock64() - t_unit0);
@@ -1752,18 +1835,528 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     }
 }
 
+// ===================================================================================
+// FUSED kernels: one launch = ONE kernel (trace + shading + stable compaction).
+//
+// The split into a geometry kernel and a shading kernel pays where the geometry is heavy (a table
+// of hundreds of triangles: the trace kernel then runs at 7-8 waves/SIMD with nothing but a ray in
+// its registers).  Where it is light it only costs traffic and launches: at launch 0 (no shadow
+// rays, state generated in registers) the pair reads the 12-byte direction twice and moves 8 bytes
+// of trace result per ray through HBM to hand a triangle index from one kernel to the next; on a
+// table of one culling round the same holds for every launch.  Fused, a launch reads its input
+// once and writes records and survivors once.
+//
+// What made the split necessary was the STABLE compaction -- a survivor's place in the next live
+// list is (survivors of all earlier chunks) + (rank in its chunk), and the first term needs every
+// earlier chunk's count.  Here it comes from SUMS ON THREE LEVELS, one workgroup per 256-entry chunk:
+//   * as soon as a chunk knows its count c it stores (DONE | c) in its own status word;
+//   * the prefix of chunk i = sum of the supergroups (4096 chunks) before its own + sum of the groups
+//     (64 chunks) before its own inside its supergroup + sum of the chunks before it inside its
+//     group: at most 64 (128) words per level, all loaded at once by one wave, polled until DONE;
+//   * the LAST chunk of a group polls all other chunk words of its group anyway: when they are done
+//     it stores (DONE | group total) in the group's word; the last chunk of a supergroup does the
+//     same with the group words for the supergroup's word.  One writer per word: plain stores.
+// So a chunk waits for the traces of the chunks in front of it (the stragglers among them) plus one
+// round trip (three near a supergroup boundary), and nothing is a chain.  Tried first: a chained
+// scan ("decoupled look-back") walks ~30 dependent rounds back through the ~1 800 workgroups in
+// flight (1.6x slower than two kernels), and sums kept by atomic adds into per-group / per-
+// supergroup words serialise at ~60 ns per add on the hot words (C4: 4 ms).
+// All words are written and read with relaxed agent-scope stores and loads (sc1: they bypass the
+// per-XCD L2), so no fence and no L2 write-back are involved -- the fence is what made a "last
+// workgroup scans" hand-off cost 0.5 ms on this 8-XCD part.  Progress: workgroups are dispatched in
+// index order, a chunk only ever waits for lower-numbered chunks, and those never wait for it; one
+// chunk per workgroup, no grid-stride loop (a resident workgroup must never wait for a chunk whose
+// workgroup still needs a slot).  The shading of a chunk's hits sits between "publish" and "sum",
+// which hides most of the wait.
+// ===================================================================================
+__device__ __forceinline__ void los_pairs(const hrt_kparams &P, const uint32_t block);   // (below)
+
+constexpr uint32_t kLbDone = 1u << 31;
+// words of launch b (u32, from the launch's base): [nc chunk words][nc/64 group words][128 supergroup
+// words]; nc = lb_chunks (a multiple of 64); the host sizes and zeroes them (hrt_layout_query).
+// (128 supergroups: 128 * 4096 chunks = 1.3e8 entries, beyond the 7.1e7 a shard can hold)
+
+__device__ __forceinline__ uint32_t lb_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lb_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct LbWords { uint32_t *chunk, *group, *super; };
+__device__ __forceinline__ LbWords lb_words(const hrt_kparams &P, uint32_t b)
+{
+    LbWords W;
+    W.chunk = reinterpret_cast<uint32_t *>(P.ws + P.off_lb) + (uint64_t)b * P.lb_stride;
+    W.group = W.chunk + P.lb_chunks;
+    W.super = W.group + P.lb_chunks / 64u;
+    return W;
+}
+
+// Exclusive prefix of `chunk` (survivors of all earlier chunks); c = the chunk's own count (already
+// published in its word).  Called by all 64 lanes of ONE wave (uniform control flow); the result is
+// wave-uniform.
+__device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chunk, uint32_t c, uint32_t lane)
+{
+    const uint32_t g = chunk >> 6, sg = chunk >> 12;
+    const bool want_c = (g << 6) + lane < chunk, want_g = (sg << 6) + lane < g;
+    const bool want_s0 = lane < sg, want_s1 = lane + 64u < sg;
+    bool g_owed = (chunk & 63u) == 63u, s_owed = (chunk & 4095u) == 4095u;   // this chunk closes its group / supergroup
+    for (;;) {
+        // (all four loads are in flight together)
+        const uint32_t cw = want_c ? lb_load(W.chunk + (g << 6) + lane) : kLbDone;
+        const uint32_t gw = want_g ? lb_load(W.group + (sg << 6) + lane) : kLbDone;
+        const uint32_t s0 = want_s0 ? lb_load(W.super + lane) : kLbDone;
+        const uint32_t s1 = want_s1 ? lb_load(W.super + lane + 64u) : kLbDone;
+        const bool ok_c = HRT_BALLOT(!(cw & kLbDone)) == 0ull, ok_g = HRT_BALLOT(!(gw & kLbDone)) == 0ull;
+        const bool ok_s = HRT_BALLOT(!(s0 & s1 & kLbDone)) == 0ull;
+        uint32_t sum_c = 0u, sum_g = 0u;
+        if (ok_c && (g_owed || (ok_g && ok_s))) sum_c = wave_sum_u32(cw & ~kLbDone);
+        if (ok_c && g_owed) {
+            if (lane == 0) lb_store(W.group + g, kLbDone | (sum_c + c));
+            g_owed = false;
+        }
+        if (ok_c && ok_g && (s_owed || ok_s)) sum_g = wave_sum_u32(gw & ~kLbDone);
+        if (ok_c && ok_g && s_owed) {
+            if (lane == 0) lb_store(W.super + sg, kLbDone | (sum_g + sum_c + c));
+            s_owed = false;
+        }
+        if (ok_c && ok_g && ok_s) return sum_c + sum_g + wave_sum_u32((s0 & ~kLbDone) + (s1 & ~kLbDone));
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+// LDS image shared by the fused kernels (hrt_hip_launch_fused sizes it):
+// [T x 5 float4 rows | T float2 guard pairs, padded to 16 B | 2 float4 per leaf] (only if staged)
+// [num_rx float4 RX pos][4 waves x 16 u64 masks][4 waves x 16 float4 leaf constants][64 u32]
+// [17 x 4 float4 materials][64 float4 TX pos]
+constexpr uint32_t kLdsTx = 64u;
+struct FusedLds {
+    float4 *tri, *leaf, *rx, *wleaf, *mat, *tx;
+    float2 *tg;
+    unsigned long long *mask;
+    uint32_t *wcnt;
+};
+template <bool TRI_IN_LDS>
+__device__ __forceinline__ FusedLds fused_lds(float4 *lds, uint32_t T, uint32_t n_leaf, uint32_t num_rx, uint32_t wave)
+{
+    FusedLds L;
+    L.tri = lds;
+    L.tg = reinterpret_cast<float2 *>(lds + HRT_ROW * T);
+    L.leaf = lds + HRT_ROW * T + (T + 1u) / 2u;
+    L.rx = TRI_IN_LDS ? L.leaf + 2u * n_leaf : lds;
+    unsigned long long *m0 = reinterpret_cast<unsigned long long *>(L.rx + num_rx);
+    L.mask = m0 + wave * kMaskRounds;
+    float4 *w0 = reinterpret_cast<float4 *>(m0 + (HRT_BLOCK / 64u) * kMaskRounds);
+    L.wleaf = w0 + wave * kMaskRounds;
+    L.wcnt = reinterpret_cast<uint32_t *>(w0 + (HRT_BLOCK / 64u) * kMaskRounds);
+    L.mat = reinterpret_cast<float4 *>(L.wcnt + 64);
+    L.tx = L.mat + 4u * HRT_NUM_MATERIALS;   // the first kLdsTx TX positions (launch 0)
+    return L;
+}
+
+// The bounce itself for a ray that hit triangle `ptri` at distance `pt` (src/compute_paths.c:
+// 611-659): incidence angle, Fresnel, free-space loss, delay, reflection.  Same sequence as the
+// shade kernel's; `tri` is the table in LDS or in global memory.
+template <typename TriPtr>
+__device__ __forceinline__ void bounce_update(TriPtr tri, Rsrc mesh_r, const float4 *l_mat, float fsl_mult,
+                                              uint32_t ptri, float pt, F3 &o, F3 &d, float &a0, float &a1,
+                                              float &a2, float &a3, float &tau, float &nth)
+{
+    const float4 q2 = tri[HRT_ROW * ptri + 2];
+    const F3 n = {q2.y, q2.z, q2.w};
+    nth = incidence_angle(n, d);
+    const uint32_t mesh = __float_as_uint(tri[HRT_ROW * ptri + 4].w);
+    const uint32_t mat = ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
+    float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
+    float fsl = fsl_mult * pt;
+    fsl *= fsl;
+    if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
+    const float b0 = a0 * R.x - a1 * R.y;
+    const float b1 = a0 * R.y + a1 * R.x;
+    const float b2 = a2 * R.z - a3 * R.w;
+    const float b3 = a2 * R.w + a3 * R.z;
+    a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+    tau += pt / kC;
+    o = add3(mul3(d, pt), o);
+    const float dn = dot3(d, n);
+    d = sub3(d, mul3(n, 2.f * dn));
+    o = add3(o, mul3(d, 1e-4f));
+}
+
+__device__ __forceinline__ void store_survivor(Rsrc out, uint32_t cap4, uint32_t k4, uint32_t ray, uint32_t ntri,
+                                               float nth, float fs0, F3 o, F3 d, float a0, float a1, float a2,
+                                               float a3, float tau)
+{
+    stf(out, H_RAY * cap4, k4, __uint_as_float(ray));
+    stf(out, H_TRI * cap4, k4, __uint_as_float(ntri));
+    stf(out, H_THETA * cap4, k4, nth);
+    stf(out, H_FS0 * cap4, k4, fs0);
+    stf(out, H_OX * cap4, k4, o.x);
+    stf(out, H_OY * cap4, k4, o.y);
+    stf(out, H_OZ * cap4, k4, o.z);
+    stf(out, H_DX * cap4, k4, d.x);
+    stf(out, H_DY * cap4, k4, d.y);
+    stf(out, H_DZ * cap4, k4, d.z);
+    stf(out, H_A0 * cap4, k4, a0);
+    stf(out, H_A1 * cap4, k4, a1);
+    stf(out, H_A2 * cap4, k4, a2);
+    stf(out, H_A3 * cap4, k4, a3);
+    stf(out, H_TAU * cap4, k4, tau);
+}
+
+constexpr uint32_t kShortList = 256u * 1024u;   // entries: one packet per wave fills the chip once
+#ifndef HRT_FUSED_WAVES0
+#define HRT_FUSED_WAVES0 5   /* launch 0: at most 96 VGPRs (100 round up to 104: four waves) */
+#endif
+#ifndef HRT_FUSED_WAVESB
+#define HRT_FUSED_WAVESB 4
+#endif
+// Launch b as one kernel.  b == 0 (FIRST): the launch set (src/compute_paths.c:442-472 state init,
+// :596-664 the first bounce).  b >= 1 (tables of one culling block): per entry of the live list the
+// num_rx shadow rays of bounce b-1 IN ORDER with the theta carry (:671-723, quirks Q6-Q8), and
+// bounce b.  A wave is a ray packet for every one of its traces (closest_hit).
+//
+// A workgroup owns a MACRO-CHUNK of K * 256 consecutive entries, K per thread (sub-chunk k =
+// entries k*256 .. k*256+255 of the macro-chunk, so a wave's k-th packet is 64 consecutive entries).
+// The launch is bound by the latency chain of a workgroup -- parameters, table staging, state loads,
+// the wait for the chunks in front, stores: ~14 us against ~1.5 us of instructions per packet -- so
+// K packets per wave share the chain (their loads are in flight together) and the grid is K times
+// smaller (an empty workgroup of a later launch still costs its dispatch: 17 us for the 62 500 of
+// C4 at K = 1).  Order inside a workgroup: (1) state loads; (2) the K bounce traces, count of the
+// survivors, publish; (3) b >= 1: shadow traces + records of the K entries -- the chunks in front
+// publish meanwhile; (4) prefix of the macro-chunk; (5) Fresnel / reflection of the survivors and
+// their stores at (prefix + rank): sub-chunk-major, i.e. in entry order (stable).
+template <bool TRI_IN_LDS, int VARIANT, bool FIRST, int K>
+__global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WAVESB)) void hrt_fused_kernel(const hrt_kparams P, const uint32_t b)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t *counts = reinterpret_cast<uint32_t *>(P.ws + P.off_counts);
+    if (FIRST && blockIdx.x >= gridDim.x - P.los_blocks) {   // the LoS pass rides along (src/compute_paths.c:515-577)
+        los_pairs(P, blockIdx.x - (gridDim.x - P.los_blocks));
+        return;
+    }
+    const uint32_t n_in = FIRST ? P.n0 : counts[b];
+    // A SHORT list is bound by the latency of one workgroup, not by throughput: then a workgroup takes
+    // one packet per wave (macro-chunk = 256 entries), which spreads the list over K times as many CUs
+    // (the grid covers ceil(cap / (256 K)) macro-chunks, so this needs n_in <= grid * 256).
+    const uint32_t n_grid = gridDim.x - (FIRST ? P.los_blocks : 0u);
+    const uint32_t Ke = (K > 1 && n_in <= kShortList && (uint64_t)n_grid * HRT_BLOCK >= n_in) ? 1u : (uint32_t)K;
+    const uint32_t MC = Ke * HRT_BLOCK;          // entries per macro-chunk
+    const uint32_t n_chunks = (n_in + MC - 1u) / MC;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= n_chunks) return;
+    const bool do_trace = FIRST || (b < P.num_bounces);
+    // All workgroups of the first generation start together, and a chunk cannot finish before the
+    // chunks in front of it have published: left alone the whole grid then runs in lock step -- every
+    // resident workgroup loads, traces, waits and stores at the same time, memory idle while the
+    // SIMDs work and vice versa.  The first generation therefore starts on a ramp (workgroup i
+    // i * stagger_clk cycles late); a slot that frees starts the next chunk, so the ramp carries on.
+    if (chunk < P.stagger_n && n_chunks > 2u * P.stagger_n)
+        for (uint32_t q = (chunk * P.stagger_clk) >> 10; q != 0u; --q) __builtin_amdgcn_s_sleep(16);   // 16 * 64 clocks
+
+    const uint32_t T = P.num_tri;
+    const uint32_t cap4 = (uint32_t)P.cap * 4u;
+    const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+    const float2 *g_tg = reinterpret_cast<const float2 *>(P.acc.tg);
+    const float4 *g_leaf = reinterpret_cast<const float4 *>(P.acc.leaf);
+    const uint32_t n_leaf = P.acc.num_leaf;
+    const FusedLds L = fused_lds<TRI_IN_LDS>(lds, T, n_leaf, P.num_rx, wave);
+#ifdef HRT_PHASE_STATS
+    // (make EXTRA=-DHRT_PHASE_STATS) time stamps of a workgroup's life (thread 0, 100 MHz wall clock):
+    // g_phase[chunk] = {start, loads + staging done, traces + publish done, records done, prefix
+    // known, stores issued}; launch HRT_PHASE_BOUNCE only (hrt_hip_read_stats dumps them to HRT_PHASE_FILE)
+    int ph_i = 0;
+#define HRT_PHASE(col)                                                                           \
+    do {                                                                                         \
+        if (tid == 0 && b == P.stagger_clk && chunk < 65536u) g_phase[chunk][ph_i++] = wall_clock64(); \
+    } while (0)
+    HRT_PHASE(0);
+#else
+#define HRT_PHASE(col) do { } while (0)
+#endif
+
+    // ---- (1) ray state of the K entries: requested before the table staging, so that both are in flight ----
+    // (FIRST: htri[k] holds the entry's TX; origin and launch Doppler term are formed where they are
+    // used -- the origin from the TX positions in LDS -- instead of being held in registers)
+    uint32_t ray[K], htri[K];
+    float theta[K], fs0[K], tau[K], a0[K], a1[K], a2[K], a3[K];
+    F3 o[K], d[K];
+    bool valid[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
+        const uint32_t i4 = i * 4u;
+        valid[k] = (uint32_t)k < Ke && i < n_in;
+        ray[k] = 0u; htri[k] = 0u;
+        theta[k] = 0.f; fs0[k] = 0.f; tau[k] = 0.f;
+        a0[k] = 1.f; a1[k] = 0.f; a2[k] = 1.f; a3[k] = 0.f;
+        o[k] = {0.f, 0.f, 0.f};
+        d[k] = {0.f, 0.f, 1.f};
+        if (valid[k]) {
+            if (FIRST) {
+                // src/compute_paths.c:452-455: ray i of the launch set, lane i = the i-th ray of the coherent order
+                const uint32_t tx = (P.num_tx == 1u) ? 0u : i / P.num_local;
+                const uint32_t pos = i - tx * P.num_local;
+                const uint32_t il = P.order ? P.order[pos] : pos;
+                ray[k] = tx * P.num_local + il;
+                htri[k] = tx;
+                const uint64_t row = P.dirs_in_launch_order ? pos : il;
+                d[k] = {P.dirs[3 * row], P.dirs[3 * row + 1], P.dirs[3 * row + 2]};
+            } else {
+                const Rsrc in = hit_blk(P, b - 1);
+                ray[k] = ldu(in, H_RAY * cap4, i4);
+                htri[k] = ldu(in, H_TRI * cap4, i4);
+                theta[k] = ldf(in, H_THETA * cap4, i4);
+                fs0[k] = ldf(in, H_FS0 * cap4, i4);
+                o[k] = {ldf(in, H_OX * cap4, i4), ldf(in, H_OY * cap4, i4), ldf(in, H_OZ * cap4, i4)};
+                d[k] = {ldf(in, H_DX * cap4, i4), ldf(in, H_DY * cap4, i4), ldf(in, H_DZ * cap4, i4)};
+                a0[k] = ldf(in, H_A0 * cap4, i4);
+                a1[k] = ldf(in, H_A1 * cap4, i4);
+                a2[k] = ldf(in, H_A2 * cap4, i4);
+                a3[k] = ldf(in, H_A3 * cap4, i4);
+                tau[k] = ldf(in, H_TAU * cap4, i4);
+            }
+        }
+    }
+    // origin of launch ray k (FIRST)
+    auto tx_origin = [&](int k) -> F3 {
+        const uint32_t tx = htri[k];
+        if (tx < kLdsTx) {
+            const float4 q = L.tx[tx];
+            return {q.x, q.y, q.z};
+        }
+        return {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
+    };
+
+    if (TRI_IN_LDS) {
+        // (four loads in flight per thread: a load -> store -> load chain costs a round trip per 4 KB)
+        const uint32_t n4 = HRT_ROW * T;
+        for (uint32_t k0 = tid; k0 < n4; k0 += 4u * HRT_BLOCK) {
+            const uint32_t k1 = k0 + HRT_BLOCK, k2 = k0 + 2u * HRT_BLOCK, k3 = k0 + 3u * HRT_BLOCK;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 t0 = g_tri[k0], t1 = k1 < n4 ? g_tri[k1] : z, t2 = k2 < n4 ? g_tri[k2] : z,
+                         t3 = k3 < n4 ? g_tri[k3] : z;
+            L.tri[k0] = t0;
+            if (k1 < n4) L.tri[k1] = t1;
+            if (k2 < n4) L.tri[k2] = t2;
+            if (k3 < n4) L.tri[k3] = t3;
+        }
+        if constexpr (VARIANT >= 4) {
+            for (uint32_t k = tid; k < T; k += HRT_BLOCK) L.tg[k] = g_tg[k];
+            for (uint32_t k = tid; k < 2u * n_leaf; k += HRT_BLOCK) L.leaf[k] = g_leaf[k];
+        }
+    }
+    if (!FIRST)
+        for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
+            L.rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
+    else if (tid < min(P.num_tx, kLdsTx))
+        L.tx[tid] = make_float4(P.tx_pos[3 * tid], P.tx_pos[3 * tid + 1], P.tx_pos[3 * tid + 2], 0.f);
+    {
+        const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
+        for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) L.mat[k] = g_mat[k];
+    }
+    __syncthreads();
+    auto tri = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float4 *)L.tri;
+        else return g_tri;
+    }();
+    auto tg = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float2 *)L.tg;
+        else return g_tg;
+    }();
+    auto leaf = [&]() {
+        if constexpr (TRI_IN_LDS) return (const float4 *)L.leaf;
+        else return g_leaf;
+    }();
+    const Rsrc mesh_r = make_rsrc(reinterpret_cast<const uint8_t *>(P.mesh));
+    HRT_PHASE(9);
+
+    // (tables of <= 64 triangles: apex-bound traces go through the per-cell candidate masks)
+    const bool masked = VARIANT == 2 && P.rxt.cell_mask != nullptr;
+    // ---- (2) the bounce traces (src/compute_paths.c:615), survivors counted per (sub-chunk, wave) ----
+    Hit h[K];
+    unsigned long long hm[K];
+    const LbWords W = lb_words(P, b);
+    uint32_t c_total = 0u;
+    if (do_trace) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            F3 apex = {0.f, 0.f, 0.f};
+            uint32_t apex_k = P.num_rx;
+            if (FIRST && P.rxt.num_txt != 0u) {   // the TX's direction table serves the launch packet
+                uint32_t tx = 0u;
+                if (P.num_tx != 1u) {
+                    tx = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)((chunk * MC + (uint32_t)k * HRT_BLOCK + (tid & ~63u)) / P.num_local));
+                    tx = min(tx, P.num_tx - 1u);
+                }
+                apex = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
+                apex_k = P.num_rx + tx;
+            }
+            if ((uint32_t)k >= Ke) {   // (short list: one packet per wave)
+                h[k] = {HRT_NO_HIT, 1e9f};
+                hm[k] = 0ull;
+                if (lane == 0) L.wcnt[16 + k * 4 + (int)wave] = 0u;
+                continue;
+            }
+            const F3 ok = FIRST ? tx_origin(k) : o[k];
+            if (FIRST && masked) {
+                h[k] = closest_hit_masked(tri, P.acc.orig, P.rxt, P.num_rx + htri[k], T, ok, d[k], valid[k], lane, 0);
+            } else {
+                Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
+                if constexpr (VARIANT >= 2 && VARIANT != 6) ball = origin_ball(ok, valid[k]);
+                h[k] = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, ok, d[k], valid[k], lane,
+                                            ball, false, apex, L.mask, L.wleaf, FIRST ? 0 : 1);
+            }
+            hm[k] = HRT_BALLOT(valid[k] && h[k].tri != HRT_NO_HIT);
+            if (lane == 0) L.wcnt[16 + k * 4 + (int)wave] = (uint32_t)__popcll(hm[k]);
+        }
+        __syncthreads();
+        // (L.wcnt[16 ..]: K x 4 counts, sub-chunk-major = entry order)
+#pragma unroll
+        for (int q = 0; q < 4 * K; ++q) c_total += L.wcnt[16 + q];
+        if (tid == 0) lb_store(W.chunk + chunk, kLbDone | c_total);
+    }
+    HRT_PHASE(10);
+
+    // ---- (3) scatter records of bounce b-1: shadow ray to every RX, in order ----
+    if constexpr (!FIRST) {
+        const uint32_t pb = b - 1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
+            const uint32_t i4 = i * 4u;
+            if (HRT_BALLOT(valid[k]) == 0ull) continue;   // wave-uniform: past the end of the list
+            const Ball ball = (VARIANT >= 2 && VARIANT != 6 && !masked) ? origin_ball(o[k], valid[k])
+                                                                       : Ball{{0.f, 0.f, 0.f}, 0.f, false};
+            F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
+            float mat_s = 0.f, mat_alpha = 1.f, th = theta[k];
+            if (valid[k]) {
+                uint32_t ht = htri[k];
+                if (ht >= T) {   // cannot happen; never fault
+                    atomicOr(&counts[P.num_bounces + 1], 4u);
+                    ht = 0u;
+                }
+                const float4 q2 = tri[HRT_ROW * ht + 2];
+                n = {q2.y, q2.z, q2.w};
+                const uint32_t mesh = __float_as_uint(tri[HRT_ROW * ht + 4].w);
+                const float4 mm = gather4(mesh_r, HRT_MESH_FLOATS * 4u, mesh, 0u);
+                mvel = {mm.x, mm.y, mm.z};
+                const float4 m3 = L.mat[4u * __float_as_uint(mm.w) + 3u];
+                mat_s = m3.x;
+                mat_alpha = m3.y;
+            }
+            for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
+                const float4 rp = L.rx[rx];
+                const F3 apex = {rp.x, rp.y, rp.z};
+                float d2rx;
+                F3 w = shadow_dir(o[k], apex, d2rx);
+                if (!valid[k]) w = {0.f, 0.f, 1.f};
+                const Hit sh = masked ? closest_hit_masked(tri, P.acc.orig, P.rxt, rx, T, o[k], w, valid[k], lane, 2)
+                                      : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, rx, P.acc.orig, T, o[k], w, valid[k],
+                                                             lane, ball, true, apex, L.mask, L.wleaf, 2);
+                bool unblocked = false;
+                if (valid[k]) {
+                    const Rsrc rec = rec_blk(P, pb, rx);
+                    if (sh.tri != HRT_NO_HIT) {
+                        const float4 s2 = tri[HRT_ROW * sh.tri + 2];
+                        th = incidence_angle({s2.y, s2.z, s2.w}, w);
+                    }
+                    if (sh.tri != HRT_NO_HIT && sh.t <= 1.f) {
+                        stf(rec, R_A0 * cap4, i4, 0.f);
+                        stf(rec, R_A1 * cap4, i4, 0.f);
+                        stf(rec, R_A2 * cap4, i4, 0.f);
+                        stf(rec, R_A3 * cap4, i4, 0.f);
+                        stf(rec, R_TAU * cap4, i4, 0.f);
+                    } else {
+                        unblocked = true;
+                        const float th_s = acos_f_ool(dot3(w, n));
+                        const float4 S = scatter_pattern(mat_s, mat_alpha, th_s, th);
+                        float o0 = a0[k] * S.x - a1[k] * S.y;
+                        float o1 = a0[k] * S.y + a1[k] * S.x;
+                        float o2 = a2[k] * S.z - a3[k] * S.w;
+                        float o3 = a2[k] * S.w + a3[k] * S.z;
+                        float f2 = P.fsl_mult * d2rx;
+                        f2 *= f2;
+                        if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
+                        stf(rec, R_A0 * cap4, i4, o0);
+                        stf(rec, R_A1 * cap4, i4, o1);
+                        stf(rec, R_A2 * cap4, i4, o2);
+                        stf(rec, R_A3 * cap4, i4, o3);
+                        stf(rec, R_TAU * cap4, i4, tau[k] + d2rx / kC);
+                        stf(rec, R_DX * cap4, i4, -w.x);
+                        stf(rec, R_DY * cap4, i4, -w.y);
+                        stf(rec, R_DZ * cap4, i4, -w.z);
+                        stf(rec, R_DFS * cap4, i4, dot3(sub3(w, d[k]), mvel) * P.dop_mult);
+                    }
+                }
+                const unsigned long long um = HRT_BALLOT(unblocked);
+                if (lane == 0 && valid[k]) mask_words(P, pb, rx)[i >> 6] = um;
+            }
+        }
+    }
+
+    HRT_PHASE(11);
+    // ---- (4) survivors of all earlier macro-chunks, (5) the bounce itself (:616-659) and the stores ----
+    if (do_trace) {
+        if (tid < 64u) {   // wave 0
+            const uint32_t excl = lb_exclusive(W, chunk, c_total, lane);
+            if (lane == 0) {
+                L.wcnt[8] = excl;
+                if (chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length
+            }
+        }
+        __syncthreads();
+        HRT_PHASE(12);
+        uint32_t pos = L.wcnt[8];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            // survivors of this wave's k-th packet start behind those of (k, earlier waves)
+            uint32_t before = 0u, sub = 0u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t cw = L.wcnt[16 + k * 4 + w];
+                before += ((uint32_t)w < wave) ? cw : 0u;
+                sub += cw;
+            }
+            const bool hit = valid[k] && h[k].tri != HRT_NO_HIT;
+            if (hit) {
+                float nth = 0.f;
+                if (FIRST) {   // src/compute_paths.c:460-466 state init, :494-500 the launch Doppler term
+                    const uint32_t tx = htri[k];
+                    o[k] = tx_origin(k);
+                    const F3 tv = {P.tx_vel[3 * tx], P.tx_vel[3 * tx + 1], P.tx_vel[3 * tx + 2]};
+                    fs0[k] = dot3(tv, d[k]) * P.dop_mult;
+                }
+                bounce_update(tri, mesh_r, L.mat, P.fsl_mult, h[k].tri, h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k],
+                              tau[k], nth);
+                const uint32_t k4 = (pos + before + lane_prefix(hm[k])) * 4u;
+                store_survivor(hit_out(P, b), cap4, k4, ray[k], h[k].tri, nth, fs0[k], o[k], d[k], a0[k], a1[k], a2[k],
+                               a3[k], tau[k]);
+            }
+            pos += sub;
+        }
+        HRT_PHASE(13);
+    }
+#undef HRT_PHASE
+}
+
 // LoS pass (src/compute_paths.c:515-577): one WAVE per (rx, tx) pair, the lanes share the
 // triangle loop (lane l tests triangles l, l+64, ... with the reference's plain sequence), then
 // a lexicographic (distance, index) minimum over the wave -- the same winner as the reference's
 // sequential scan with its strict '<' (lowest index on equal distance).
 // Output per pair: HRT_LOS_FLOATS floats {status, a, tau, dir_tx xyz, freq_shift, -}.
-__global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
+__device__ __forceinline__ void los_pairs(const hrt_kparams &P, const uint32_t block)
 {
     const float4 *tri = reinterpret_cast<const float4 *>(P.tri);
     float *out = reinterpret_cast<float *>(P.ws + P.off_los);
     const uint32_t n = P.num_rx * P.num_tx;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t off = blockIdx.x * (HRT_BLOCK / 64u) + (threadIdx.x >> 6);
+    const uint32_t off = block * (HRT_BLOCK / 64u) + (threadIdx.x >> 6);
     if (off >= n) return;   // whole wave
     const uint32_t rx = off / P.num_tx, tx = off - rx * P.num_tx;
     const F3 o = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
@@ -1827,6 +2420,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
         q[1] = a; q[2] = tau; q[3] = u.x; q[4] = u.y; q[5] = u.z; q[6] = fs; q[7] = 0.f;
     }
 }
+__global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P) { los_pairs(P, blockIdx.x); }
 
 // ===================================================================================
 // Launch directions on the device.  The reference evaluates
@@ -2104,6 +2698,43 @@ static void launch_trace_t(const hrt_kparams *P, uint32_t bounce, uint32_t block
                        bounce);
 }
 
+// launch `bounce` as ONE kernel (hrt_fused_kernel): one workgroup per macro-chunk of K * 256 entries
+#ifndef HRT_FUSED_K0
+#define HRT_FUSED_K0 4   /* packets per wave at launch 0 */
+#endif
+#ifndef HRT_FUSED_KB
+#define HRT_FUSED_KB 2   /* ... at later launches (15 words of state per entry stay in registers) */
+#endif
+template <bool LDS, int V>
+static void launch_fused_t(const hrt_kparams *P, uint32_t bounce, size_t lds, hipStream_t st, hipError_t *err)
+{
+    const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
+    if (bounce == 0) {
+        constexpr int K = HRT_FUSED_K0;
+        // (a short launch set: one packet per wave, see the kernel) + the workgroups of the LoS pass
+        const uint32_t blocks = (uint32_t)((n_max + (n_max <= kShortList ? 1 : K) * HRT_BLOCK - 1) /
+                                           ((n_max <= kShortList ? 1 : K) * HRT_BLOCK)) + P->los_blocks;
+        if (lds > 64u * 1024u) {
+            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_fused_kernel<LDS, V, true, K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (*err != hipSuccess) return;
+        }
+        hipLaunchKernelGGL((hrt_fused_kernel<LDS, V, true, K>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P, bounce);
+    } else if constexpr (LDS && (V == 0 || V == 1 || V == 2 || V == 4)) {   // later launches: one-block tables in LDS
+        constexpr int K = HRT_FUSED_KB;
+        const uint32_t kk = n_max <= kShortList ? 1u : (uint32_t)K;
+        const uint32_t blocks = (uint32_t)((n_max + kk * HRT_BLOCK - 1) / (kk * HRT_BLOCK));
+        if (lds > 64u * 1024u) {
+            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_fused_kernel<LDS, V, false, K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (*err != hipSuccess) return;
+        }
+        hipLaunchKernelGGL((hrt_fused_kernel<LDS, V, false, K>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P, bounce);
+    } else {
+        *err = hipErrorNotSupported;   // later launches are fused on one-block tables in LDS only: the host falls back
+    }
+}
+
 thread_local char g_err[256];
 
 }  // namespace
@@ -2238,6 +2869,59 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
     return (int)hipGetLastError();
 }
 
+int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
+{
+    hrt_kparams Pc = *P_in;
+    static const uint64_t stag_n = env_u64("HRT_STAGGER_N", 0), stag_clk = env_u64("HRT_STAGGER_CLK", 0);
+    Pc.stagger_n = (uint32_t)stag_n;
+    Pc.stagger_clk = (uint32_t)stag_clk;
+    if (bounce != 0) Pc.los_blocks = 0;
+    else if (Pc.los_blocks) Pc.los_blocks = (Pc.num_rx * Pc.num_tx + HRT_BLOCK / 64u - 1u) / (HRT_BLOCK / 64u);
+#ifdef HRT_PHASE_STATS
+    Pc.stagger_n = 0;
+    Pc.stagger_clk = (uint32_t)env_u64("HRT_PHASE_BOUNCE", 0);
+#endif
+    const hrt_kparams *P = &Pc;
+    if (P->cap / HRT_BLOCK + 1u > P->lb_chunks) return (int)hipErrorInvalidValue;   // (one word per chunk)
+    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
+    const uint64_t T = P->num_tri;
+    const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
+                               (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
+    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
+    const bool one_block = P->num_tri <= kMaskRounds * 64u;
+    const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
+                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 16u) + 64u * 4u +
+                       (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + kLdsTx * 16u;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    // the same choice of intersection loop as hrt_hip_launch_trace; on tables of a handful of
+    // triangles (auto) the staged walk over all of them is cheaper than a culling round
+    static const uint64_t staged_max = env_u64("HRT_FUSE_STAGED_MAX_TRI", 6);
+    const bool trees = P->acc.big && (variant >= 4);
+    const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
+    const bool staged = variant == 1 || (variant == 7 && T <= staged_max);
+    if (in_lds) {
+        if (variant == 0) launch_fused_t<true, 0>(P, bounce, lds, st, &err);
+        else if (staged) launch_fused_t<true, 1>(P, bounce, lds, st, &err);
+        else if (flat) {
+            if (one_block) launch_fused_t<true, 2>(P, bounce, lds, st, &err);
+            else launch_fused_t<true, 3>(P, bounce, lds, st, &err);
+        } else if (trees) launch_fused_t<true, 6>(P, bounce, lds, st, &err);
+        else if (one_block) launch_fused_t<true, 4>(P, bounce, lds, st, &err);
+        else launch_fused_t<true, 5>(P, bounce, lds, st, &err);
+    } else {
+        if (variant == 0) launch_fused_t<false, 0>(P, bounce, lds, st, &err);
+        else if (staged) launch_fused_t<false, 1>(P, bounce, lds, st, &err);
+        else if (flat) launch_fused_t<false, 3>(P, bounce, lds, st, &err);
+        else if (trees) launch_fused_t<false, 6>(P, bounce, lds, st, &err);
+        else launch_fused_t<false, 5>(P, bounce, lds, st, &err);
+    }
+    if (err == hipErrorNotSupported) return -1;   // not a HIP failure: this launch runs as two kernels
+    if (err != hipSuccess) return (int)err;
+    return (int)hipGetLastError();
+}
+
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream)
@@ -2316,7 +3000,15 @@ int hrt_hip_selftest_math(int fn, const float *d_in, float *d_out, uint64_t n, v
 
 int hrt_hip_read_stats(unsigned long long *out, int reset)
 {
-#ifdef HRT_KERNEL_STATS
+#ifdef HRT_PHASE_STATS
+    if (const char *pf = getenv("HRT_PHASE_FILE")) {
+        static unsigned long long host_phase[65536][8];
+        if (hipMemcpyFromSymbol(host_phase, HIP_SYMBOL(g_phase), sizeof host_phase) == hipSuccess) {
+            if (FILE *f = fopen(pf, "wb")) { fwrite(host_phase, 1, sizeof host_phase, f); fclose(f); }
+        }
+    }
+#endif
+#if defined(HRT_KERNEL_STATS) || defined(HRT_PHASE_STATS)
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 3 * HRT_STATS_COLS);
     if (e != hipSuccess) return (int)e;
     if (reset) {

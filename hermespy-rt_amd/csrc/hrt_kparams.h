@@ -79,6 +79,11 @@ typedef struct {
     const float *ro_bin;            /* [num_rx + num_txt] line-point radius the lists were built for */
     const uint32_t *off;            /* [(num_rx + num_txt) * HRT_RXT_BINS + 1] */
     const uint16_t *idx;            /* table rows */
+    /* tables of at most 64 triangles: instead of lists, ONE 64-bit candidate mask per (apex, cell),
+     * built for the cell alone (no packet widening) -- a ray looks up its own cell, the wave ORs
+     * the masks of its lanes and walks the union: no origin ball, no cone, no culling round.
+     * [(num_rx + num_tx) * HRT_RXT_BINS], or NULL (then `enabled` says whether there are lists) */
+    const unsigned long long *cell_mask;
 } hrt_krxt;
 
 /* ---- re-sorting of the live list between bounces ----
@@ -128,7 +133,20 @@ typedef struct {
     uint64_t off_counts, off_los, off_hits, hit_block_bytes, off_recs, rec_block_bytes,
         off_masks, off_chunk_cnt, off_super_cnt, off_res;
     uint32_t num_super;   /* super-chunks per bounce */
+    /* status words of the fused kernels' stable compaction (hrt_kernels.hip, "counted sums"), zeroed
+     * with the counts: per launch b, from off_lb + b * lb_stride * 4: lb_chunks u32 (one per
+     * 256-entry chunk), lb_chunks / 64 u32 (groups), 128 u32 (supergroups) */
+    uint64_t off_lb;
+    uint32_t lb_stride, lb_chunks;
+    uint32_t los_blocks;  /* fused launch 0: the last los_blocks workgroups of the grid do the LoS pass (0: own kernel) */
+    uint32_t stagger_n, stagger_clk;   /* fused kernels: the first stagger_n workgroups start stagger_clk * index cycles late */
+    uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
 } hrt_kparams;
+
+/* hrt_kparams.fuse */
+#define HRT_FUSE_LAUNCH0 1u   /* launch 0 (no shadow rays, state generated in registers) */
+#define HRT_FUSE_BOUNCES 2u   /* launches 1..num_bounces too (tables of one culling block) */
+#define HRT_FUSE_MAX_TRI 64u  /* default: whole bounces are fused on tables of at most this many triangles */
 
 /* ---- the shim (hrt_kernels.hip).  All return 0 or a positive hipError_t. ---- */
 int hrt_hip_device_count(int *n);
@@ -148,6 +166,7 @@ int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_launch_fused(const hrt_kparams *P, uint32_t bounce, void *stream);   /* -1: not fusable, nothing launched */
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream);

@@ -41,7 +41,8 @@ class Layout(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "total_bytes", "cap", "off_counts", "off_los", "off_hits", "hit_block_bytes",
         "off_recs", "rec_block_bytes", "off_masks", "off_chunk_cnt", "off_super_cnt", "off_res",
-        "num_super", "off_sort_scratch", "off_sort_keys", "off_sort_tmp", "sort_tmp_bytes")]
+        "num_super", "off_sort_scratch", "off_sort_keys", "off_sort_tmp", "sort_tmp_bytes",
+        "off_lb", "lb_stride")]
 
 
 class KernelTimes(C.Structure):

@@ -161,6 +161,10 @@ typedef struct {
     /* re-sorting of the live list between bounces (only when the problem has it on, HRT_SORT_RAYS):
      * a hit-block-sized scratch, 4 x cap u32 of keys / indices, the sort's temporary storage */
     uint64_t off_sort_scratch, off_sort_keys, off_sort_tmp, sort_tmp_bytes;
+    /* status words of the fused kernels (stable compaction inside ONE kernel: per-chunk, per-group
+     * and per-supergroup survivor counts): u32 [num_bounces + 1][lb_stride], zeroed with the counts
+     * at the start of every trace */
+    uint64_t off_lb, lb_stride;
 } hrt_layout;
 
 /* HRT_E_CAPACITY when num_tx * (local rays) exceeds 2^32 / (HRT_HIT_FIELDS * 4) - 512
