@@ -719,6 +719,7 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
     if (scat_rays) D = 1;
     dev_ctx *ctx = (dev_ctx *)calloc((size_t)D, sizeof(dev_ctx));
     if (!ctx) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    const int D_created = D;   /* a problem is made for each of these, however many end up with work */
     st.device = devs[0];
     const size_t nq = ntx * np;
     int rc = HRT_OK;
@@ -924,10 +925,11 @@ done:
         if (d > 0 && ctx[d].w.h_dirs == ctx[0].w.h_dirs) ctx[d].w.h_dirs = NULL;   /* shared table */
         if (ctx[d].rc == HRT_OK && rc) ctx[d].rc = rc;
     }
-    for (int d = D - 1; d >= 0; --d) {
+    for (int d = D - 1; d >= 0; --d)
         if (ctx[d].w.d_ws || ctx[d].w.ray) hrt_worker_release(&ctx[d]);
-        hrt_problem_destroy(ctx[d].prob);
-    }
+    /* (every problem that was created: a launch set of fewer 4096-path granules than devices leaves
+     * some devices without work, but their problems exist) */
+    for (int d = (D_created > D ? D_created : D) - 1; d >= 0; --d) hrt_problem_destroy(ctx[d].prob);
     hrt_pool_end(pool_taken);
     free(ctx);
     st.t_total_s = hrt_now_s() - t_begin;

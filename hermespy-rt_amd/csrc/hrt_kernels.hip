@@ -2009,7 +2009,7 @@ __device__ __forceinline__ void store_survivor(Rsrc out, uint32_t cap4, uint32_t
 
 constexpr uint32_t kShortList = 256u * 1024u;   // entries: one packet per wave fills the chip once
 #ifndef HRT_FUSED_WAVES0
-#define HRT_FUSED_WAVES0 5   /* launch 0: at most 96 VGPRs (100 round up to 104: four waves) */
+#define HRT_FUSED_WAVES0 7   /* launch 0: at most 72 VGPRs (8 waves spill and are slower) */
 #endif
 #ifndef HRT_FUSED_WAVESB
 #define HRT_FUSED_WAVESB 4
@@ -2086,6 +2086,17 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     float theta[K], fs0[K], tau[K], a0[K], a1[K], a2[K], a3[K];
     F3 o[K], d[K];
     bool valid[K];
+    // src/compute_paths.c:452-455: ray i of the launch set, lane i = the i-th ray of the coherent order
+    auto launch_entry = [&](int k) {
+        const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
+        const uint32_t tx = (P.num_tx == 1u) ? 0u : i / P.num_local;
+        const uint32_t pos = i - tx * P.num_local;
+        const uint32_t il = P.order ? P.order[pos] : pos;
+        ray[k] = tx * P.num_local + il;
+        htri[k] = tx;
+        const uint64_t row = P.dirs_in_launch_order ? pos : il;
+        d[k] = {P.dirs[3 * row], P.dirs[3 * row + 1], P.dirs[3 * row + 2]};
+    };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
@@ -2098,14 +2109,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
         d[k] = {0.f, 0.f, 1.f};
         if (valid[k]) {
             if (FIRST) {
-                // src/compute_paths.c:452-455: ray i of the launch set, lane i = the i-th ray of the coherent order
-                const uint32_t tx = (P.num_tx == 1u) ? 0u : i / P.num_local;
-                const uint32_t pos = i - tx * P.num_local;
-                const uint32_t il = P.order ? P.order[pos] : pos;
-                ray[k] = tx * P.num_local + il;
-                htri[k] = tx;
-                const uint64_t row = P.dirs_in_launch_order ? pos : il;
-                d[k] = {P.dirs[3 * row], P.dirs[3 * row + 1], P.dirs[3 * row + 2]};
+                launch_entry(k);
             } else {
                 const Rsrc in = hit_blk(P, b - 1);
                 ray[k] = ldu(in, H_RAY * cap4, i4);
@@ -2304,7 +2308,11 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     // ---- (4) survivors of all earlier macro-chunks, (5) the bounce itself (:616-659) and the stores ----
     if (do_trace) {
         if (tid < 64u) {   // wave 0
+#ifdef HRT_EXP_NOWAIT   /* timing experiment only: WRONG offsets */
+            const uint32_t excl = chunk * MC / 2u;
+#else
             const uint32_t excl = lb_exclusive(W, chunk, c_total, lane);
+#endif
             if (lane == 0) {
                 L.wcnt[8] = excl;
                 if (chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length
@@ -2327,16 +2335,26 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
             if (hit) {
                 float nth = 0.f;
                 if (FIRST) {   // src/compute_paths.c:460-466 state init, :494-500 the launch Doppler term
+                    // ray id and direction are read AGAIN here (the lines were touched a few us ago: L2 /
+                    // MALL hits) instead of living in registers through the K traces: K * 5 registers less,
+                    // 7 waves per SIMD instead of 5 (C4 launch 0: 0.347 -> 0.309 ms)
+                    launch_entry(k);
                     const uint32_t tx = htri[k];
                     o[k] = tx_origin(k);
                     const F3 tv = {P.tx_vel[3 * tx], P.tx_vel[3 * tx + 1], P.tx_vel[3 * tx + 2]};
                     fs0[k] = dot3(tv, d[k]) * P.dop_mult;
                 }
+#ifndef HRT_EXP_NOSHADE
                 bounce_update(tri, mesh_r, L.mat, P.fsl_mult, h[k].tri, h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k],
                               tau[k], nth);
+#endif
                 const uint32_t k4 = (pos + before + lane_prefix(hm[k])) * 4u;
+#ifndef HRT_EXP_NOSTORE
                 store_survivor(hit_out(P, b), cap4, k4, ray[k], h[k].tri, nth, fs0[k], o[k], d[k], a0[k], a1[k], a2[k],
                                a3[k], tau[k]);
+#else
+                if (k4 == 0xfffffff0u) stf(hit_out(P, b), 0u, 0u, nth + o[k].x + d[k].y + a0[k] + tau[k]);
+#endif
             }
             pos += sub;
         }

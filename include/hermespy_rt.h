@@ -45,9 +45,11 @@ typedef struct {                                   /* inc/scene.h:10-27 */
     Vec3 velocity;
     Vec3 *ns;                 /* [num_triangles] unit normals; NULL after scene_load.  As in
                                  the reference (src/compute_paths.c:212) compute_paths()
-                                 malloc()s it and leaves it for free_scene(); unlike the
-                                 reference a previous allocation is free()d first (no leak on
-                                 repeated calls). */
+                                 malloc()s it and leaves it for free_scene(); like the
+                                 reference it OVERWRITES the old pointer without freeing it
+                                 (a hand-built Mesh may leave `ns` uninitialised): a caller
+                                 that calls compute_paths() repeatedly on one Scene frees
+                                 `ns` between the calls, or reloads the scene. */
 } Mesh;
 
 typedef struct { uint32_t num_meshes; Mesh *meshes; } Scene;   /* inc/scene.h:29-32 */

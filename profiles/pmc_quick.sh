@@ -17,14 +17,15 @@ python3 - <<P
 import csv, glob, collections
 for p in "AB":
     f = max(glob.glob("gpurun_out/pq_${w}_%s/*/*counter_collection.csv" % p))
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
-    seen=set()
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if "hrt_" not in k: continue
-        k = k.split("(")[0][-60:] + " g" + r["Grid_Size"]
-        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if (r["Dispatch_Id"]) not in seen: seen.add(r["Dispatch_Id"]); n[k]+=1
-    for k in acc:
-        print(p, k, "n=%d" % n[k], {c: round(v / n[k]) for c, v in acc[k].items()})
+    rows = [r for r in csv.DictReader(open(f)) if "hrt_" in r["Kernel_Name"]]
+    disp = collections.OrderedDict()
+    for r in rows:
+        d = int(r["Dispatch_Id"])
+        disp.setdefault(d, {"k": r["Kernel_Name"].split("(")[0][-28:] + ("<" + r["Kernel_Name"].split("<")[1][:16] if "<" in r["Kernel_Name"] else ""), "grid": r["Grid_Size"]})[r["Counter_Name"]] = round(float(r["Counter_Value"]))
+    los = [d for d in disp if "los" in disp[d]["k"] or "fused" in disp[d]["k"] and "true, 4" in disp[d]["k"]]
+    ids = sorted(disp)
+    # the dispatches of the last step: from the last launch-0 (largest grid first seen) on
+    last0 = max(d for d in ids if disp[d]["grid"] == disp[ids[-1 if False else 0]]["grid"]) if ids else 0
+    for d in ids:
+        if d >= last0: print(p, d, disp[d])
 P
