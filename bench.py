@@ -19,12 +19,15 @@ reported beside it, measured in the same process right after the timed region (N
                           (they are part of compute_paths in the reference, src/compute_paths.c:442-456)
     end_to_end            hrt_compute_paths_ex on host arrays, cold and warm, with its phase split
                           (setup, launch tables, device, D2H + dense scatter) -- the PCIe-inclusive figure
-    sustained             the same step repeated for >= 1 s of GPU time (the 20-step timed region is
+    sustained             the same step repeated for >= 10 s of GPU time (the 20-step timed region is
                           35 ms; this is the region a utilisation sampler can see)
 
-N > 1 (weak scaling: N GPUs trace an N-times denser Fibonacci sphere, ray-sharded round-robin in
-4096-path granules): `value` has no exchange step in it (rays are independent); the collection of
-the records is measured right after and reported as first-class numbers:
+N > 1: ray-sharded round-robin in 4096-path granules.  --scaling weak (default): N GPUs trace an
+N-times denser Fibonacci sphere (the workload's ray count per GPU); --scaling strong: the
+workload's ray count is the total -- `--workload c4 --gpus 4 --scaling strong` is BASELINE
+configs[3], `--workload c5 --gpus 8 --scaling strong` configs[4]; at N = 1 both are the same run.
+`value` has no exchange step in it (rays are independent); the collection of the records is
+measured right after and reported as first-class numbers:
 
     value_with_gather     every rank's packed records -> rank 0 over RCCL (xGMI), serialised into the step
     value_with_d2h        every rank copies its own packed records to its host over its own PCIe link
@@ -158,8 +161,13 @@ def main():
                     help="N > 1: run the RCCL gather of all records to rank 0 inside every timed step")
     ap.add_argument("--collect", choices=("gather", "d2h", "both", "none"), default="both",
                     help="N > 1: which collection step(s) to measure after the timed region")
-    ap.add_argument("--time-every", type=int, default=4,
-                    help="record the per-kernel HIP events on every n-th timed step (default 4)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every GPU traces the workload's ray count (an N-times denser sphere in "
+                         "all); strong = the workload's ray count is the TOTAL, ray-sharded over the N GPUs -- "
+                         "`--workload c4 --gpus 4 --scaling strong` is BASELINE configs[3] (16 M rays in all), "
+                         "`--workload c5 --gpus 8 --scaling strong` configs[4] (64 M)")
+    ap.add_argument("--event-steps", type=int, default=10,
+                    help="steps of the separate, untimed pass that carries the per-kernel HIP events")
     ap.add_argument("--no-gather", action="store_true", help="same as --collect none")
     ap.add_argument("--gather-timeout", type=float, default=120.0,
                     help="N > 1: give up on a collection measurement after this many seconds (exit code 3)")
@@ -167,7 +175,8 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="N = 1: skip the drop-in / launch-inclusive / sustained measurements")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--sustain-s", type=float, default=1.2, help="GPU seconds of the sustained region")
+    ap.add_argument("--sustain-s", type=float, default=10.0,
+                    help="GPU seconds of the sustained region (long enough for a utilisation sampler)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch hrt_selftest_math_kernel over 32M floats (known traffic: "
                          "128 MiB read + 128 MiB written, 4 B/lane) to calibrate PMC byte counters")
@@ -231,7 +240,9 @@ def main():
     from hermespy_rt_amd import sharding
 
     base = W.WORKLOADS[args.workload]
-    c = dict(base, num_paths=base["num_paths"] * world)   # weak scaling: denser sphere
+    # weak scaling: an N-times denser sphere, the workload's ray count per GPU; strong scaling: the
+    # workload's ray count in all, sharded (BASELINE configs[3] / [4] are stated this way)
+    c = dict(base, num_paths=base["num_paths"] * (world if args.scaling == "weak" else 1))
     tr = Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"], c["f_ghz"],
                 c["num_paths"], c["num_bounces"], rank=rank, world=world)
     gather = None
@@ -262,19 +273,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # per-kernel HIP events (one hrt_timer = the events of one step), recorded on the launch stream
-    # INSIDE the timed region and read after it -- the steps run back to back, asynchronously.
-    # Every 4th timed step carries them (all of them with --time-every 1): 17 event records per
-    # step cost ~4 % of a 1.7 ms step, and the timed region is the metric.
-    every = max(1, int(args.time_every))
-    timers = [tr.new_timer() if k % every == 0 else None for k in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(timers[k])
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -282,10 +287,15 @@ def main():
     dt = time.perf_counter() - t0
     t_all = xreduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
     dt = float(t_all.item())
+    # per-kernel HIP events (one hrt_timer = the events of one step, recorded on the launch stream,
+    # read afterwards): a SEPARATE untimed pass right after the timed region, every step of it
+    # instrumented -- the timed steps carry no events (they cost ~4 % of a 1.6 ms step)
+    timers = [tr.new_timer() for _ in range(max(1, args.event_steps))]
+    for t in timers:
+        step(t)
+    torch.cuda.synchronize()
     bounce_ms, los_ms, compact_ms, shade_ms = [], [], [], []
     for t in timers:
-        if t is None:
-            continue
         r = tr.read_timer(t)
         los_ms.append(r["los_ms"])
         bounce_ms.append(r["trace_ms"])
@@ -344,13 +354,29 @@ def main():
                         stale=vj[args.workload].get("kernels_sha16") != kern_sha)
     except (OSError, ValueError, KeyError):
         pass
-    roofline = dict(bound="hbm", kernel="hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)",
+    # which resource binds: the VALU issue rate of the dominant kernel (committed PMC pass) against
+    # the HBM fraction of the path -- C3 is VALU-bound, the tiny tables are nearer HBM
+    hbm_frac = ach / HBM_PEAK_GBS
+    valu_frac = None
+    if valu:
+        fr = [(v["valu_insts_per_step"], v["issue_frac_vs_simd32_peak"]) for k, v in valu.items()
+              if isinstance(v, dict) and "issue_frac_vs_simd32_peak" in v]
+        if fr:
+            valu_frac = max(fr)[1]   # of the kernel that issues the most instructions
+    fused0 = os.environ.get("HRT_FUSE", "") not in ("0",)
+    fused_all = fused0 and tr.num_tri <= 64
+    kern_desc = ("hrt_fused_kernel (one kernel per launch: trace + shading + stable compaction)" if fused_all else
+                 ("launch 0: hrt_fused_kernel; later launches: " if fused0 else "") +
+                 "hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)")
+    roofline = dict(bound=("valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm"), kernel=kern_desc,
                     achieved=ach, peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                    traffic_stale=traffic_stale, kernels_sha16=kern_sha,
+                    unit="GB/s", frac=hbm_frac, hbm_frac=hbm_frac, valu_frac=valu_frac,
+                    traffic=traffic, traffic_source=traffic_src,
+                    traffic_stale=traffic_stale, traffic_measured_in_run=False, kernels_sha16=kern_sha,
                     algorithmic_bytes_per_launch=B_local / n_launch,
                     avg_launch_ms=kern_ms_step / n_launch, launches_per_step=n_launch,
                     steps_with_kernel_events=int(bm.shape[0]),
+                    kernel_events="separate untimed pass after the timed region, every step instrumented",
                     per_launch_ms=[float(x) for x in bm.mean(axis=0)],
                     trace_kernel_ms=[float(x) for x in tm.mean(axis=0)],
                     shade_kernel_ms=[float(x) for x in sm.mean(axis=0)],
@@ -358,7 +384,9 @@ def main():
                     compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
                     trace_variant=os.environ.get("HRT_TRACE_VARIANT", "auto (flat packet culling; trees on big sparse tables)"),
                     valu=valu,
-                    note="VALU-bound intersection work, not HBM-bound: see DESIGN.md section 6")
+                    note=("a fused launch reports its one kernel under trace_kernel_ms (shade_kernel_ms = 0); "
+                          "frac is the north-star's HBM figure (algorithmic bytes / kernel time / 8 TB/s); "
+                          "valu_frac = VALU instructions issued x 2 cycles / SIMD-cycles of the busiest kernel"))
 
     kstats = None
     try:
@@ -374,11 +402,11 @@ def main():
         out = dict(
             metric="resolved propagation paths/sec", value=paths * args.steps / dt,
             unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-            ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
+            ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling=args.scaling if world > 1 else "weak",
             vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=W.describe(c), name=args.workload,
-                        parallelism="ray-sharded x%d, round-robin 4096-path granules%s" % (
-                            world, ", RCCL gather to rank 0 inside the step" if in_step else ""),
+                        parallelism="ray-sharded x%d (%s scaling), round-robin 4096-path granules%s" % (
+                            world, args.scaling, ", RCCL gather to rank 0 inside the step" if in_step else ""),
                         rays_total=c["num_paths"] * ntx,
                         scope="steady-state kernels: scene, endpoints and launch directions resident in HBM, "
                               "compact records left in HBM; launch-table generation, H2D/D2H and the dense "

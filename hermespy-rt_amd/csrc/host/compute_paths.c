@@ -914,6 +914,12 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
             /* phases: the slowest device */
             if (ctx[d].t_dev > st.t_device_s) st.t_device_s = ctx[d].t_dev;
             if (ctx[d].t_rb > st.t_readback_s) st.t_readback_s = ctx[d].t_rb;
+            if (d < 16) {
+                st.dev_id[d] = ctx[d].device;
+                st.dev_batches[d] = (G - (uint32_t)d + (uint32_t)D - 1u) / (uint32_t)D;   /* batches d, d + D, ... */
+                st.dev_t_device_s[d] = ctx[d].t_dev;
+                st.dev_t_readback_s[d] = ctx[d].t_rb;
+            }
             st.t_launch_dirs_s += ctx[d].t_launch / D;
         }
     }

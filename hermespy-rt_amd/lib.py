@@ -56,7 +56,8 @@ class Stats(C.Structure):
                 ("t_setup_s", C.c_double), ("t_launch_dirs_s", C.c_double),
                 ("t_device_s", C.c_double), ("t_readback_s", C.c_double),
                 ("t_total_s", C.c_double), ("device", C.c_int), ("num_devices", C.c_int),
-                ("num_batches", C.c_uint32)]
+                ("num_batches", C.c_uint32), ("dev_id", C.c_int * 16), ("dev_batches", C.c_uint32 * 16),
+                ("dev_t_device_s", C.c_double * 16), ("dev_t_readback_s", C.c_double * 16)]
 
 
 class HrtError(RuntimeError):

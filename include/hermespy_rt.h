@@ -111,6 +111,12 @@ typedef struct {
     int device;               /* the first device used */
     int num_devices;          /* devices the batches were dealt to (HRT_DEVICES) */
     uint32_t num_batches;     /* round-robin shards of the launch set the call was cut into */
+    /* per device d < num_devices (HRT_DEVICES order; at most 16): its id, the batches it took, the
+     * time its thread spent waiting for its kernels and in readback + dense scatter -- on a node
+     * with several GPUs these show the balance of the call */
+    int dev_id[16];
+    uint32_t dev_batches[16];
+    double dev_t_device_s[16], dev_t_readback_s[16];
 } hrt_stats;
 
 /* Same as compute_paths() but returns 0 / a negative HRT_E_* code instead of exiting, takes

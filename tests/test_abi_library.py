@@ -120,3 +120,62 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     deps = subprocess.check_output(["ldd", lib.LIB_PATH], text=True)
     assert "oracle" not in deps
+
+
+REF_INC = "/root/reference/inc"
+
+CALLER_SRC = r'''
+/* a caller written against the REFERENCE's headers only (INTEGRATION.md section 1) */
+#include "compute_paths.h"
+#include "scene.h"
+#include <stdio.h>
+#include <string.h>
+int main(int argc, char **argv)
+{
+    Scene s = scene_load(argv[1]);
+    if (s.num_meshes != 1 || s.meshes[0].num_triangles != 12 || s.meshes[0].ns != NULL) return 2;
+    scene_save(&s, argv[2]);
+    /* the entry point resolves against the product library (calling it needs a GPU) */
+    void (*fp)(Scene *, Vec3 *, Vec3 *, Vec3 *, Vec3 *, float, size_t, size_t, size_t, size_t, ChannelInfo *,
+               RaysInfo *, ChannelInfo *, RaysInfo *) = compute_paths;
+    if (argc > 3) {   /* GPU box: one tiny call, box.hrt, the SURVEY 8c anchor inputs */
+        Vec3 rx = {2, 1, 1.5f}, tx = {0, 0, 2.5f}, z = {0, 0, 0};
+        enum { NP = 1000 };
+        static Vec3 dl_rx[1], dl_tx[1], ds_rx[NP], ds_tx[NP];
+        static float l[6][1], sc[6][NP];
+        ChannelInfo los = {1, dl_rx, dl_tx, l[0], l[1], l[2], l[3], l[4], l[5]};
+        ChannelInfo scat = {NP, ds_rx, ds_tx, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]};
+        static Ray lr[1], sr[2 * NP];
+        static uint8_t la[8], sa[2 * (NP / 8 + 1)];
+        RaysInfo rl = {1, 1, lr, la}, rs = {1, NP, sr, sa};
+        fp(&s, &rx, &tx, &z, &z, 3.0f, 1, 1, NP, 1, &los, &rl, &scat, &rs);
+        printf("los_tau %.9g a %.9g\n", l[4][0], l[0][0]);
+        if (!s.meshes[0].ns) return 3;
+    }
+    free_scene(&s);
+    printf("caller ok %p\n", (void *)fp);
+    return 0;
+}
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="needs the reference headers (build container only)")
+def test_caller_built_against_reference_headers_links_unchanged(tmp_path):
+    """INTEGRATION.md section 1, literally: a C caller compiled with -I/root/reference/inc (not our
+    headers) links against libhermespy_rt_amd.so and runs: scene_load returns the reference's Scene
+    by value, scene_save writes the same bytes, compute_paths resolves (and, with a GPU, is called
+    and returns the SURVEY 8c LoS anchor)."""
+    src = tmp_path / "caller.c"
+    src.write_text(CALLER_SRC)
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", REF_INC, str(src), "-o", str(exe), "-L", libdir,
+                           "-lhermespy_rt_amd", "-Wl,-rpath," + libdir, "-lm"])
+    box = os.path.join(REPO, "scenes", "box.hrt")
+    out = tmp_path / "again.hrt"
+    args = [str(exe), box, str(out)] + (["gpu"] if _have_gpu() else [])
+    p = subprocess.run(args, capture_output=True, text=True)
+    assert p.returncode == 0 and "caller ok" in p.stdout, (p.returncode, p.stdout, p.stderr[-500:])
+    assert open(out, "rb").read() == open(box, "rb").read()
+    if _have_gpu():
+        assert "los_tau 8.17061885e-09 a 0.00324648875" in p.stdout, p.stdout

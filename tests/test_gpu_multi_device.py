@@ -35,6 +35,11 @@ for c, rays in ((K.small(K.C3, 70000), False), (K.small(K.C4_DOPPLER, 30001), Fa
     want = 1 if rays else min(%(want)d, (c["num_paths"] + 4095) // 4096)   # a batch is at least one 4096-path granule
     assert st.num_devices == want, (st.num_devices, want, st.num_batches)
     assert st.num_batches %% st.num_devices == 0
+    # per-device phase times and batch counts (what shows the balance on a node with several GPUs)
+    nd = st.num_devices
+    assert sum(int(st.dev_batches[d]) for d in range(nd)) == st.num_batches
+    assert all(int(st.dev_id[d]) == 0 and st.dev_t_device_s[d] > 0 and st.dev_t_readback_s[d] > 0 for d in range(nd))
+    assert abs(max(st.dev_t_device_s[d] for d in range(nd)) - st.t_device_s) < 1e-12
     assert [int(st.live[i]) for i in range(c["num_bounces"] + 1)] == [int(x) for x in ref["extras"]["live"]]
 print("MULTI_OK")
 """
