@@ -1959,17 +1959,22 @@ __device__ __forceinline__ FusedLds fused_lds(float4 *lds, uint32_t T, uint32_t 
 
 // The bounce itself for a ray that hit triangle `ptri` at distance `pt` (src/compute_paths.c:
 // 611-659): incidence angle, Fresnel, free-space loss, delay, reflection.  Same sequence as the
-// shade kernel's; `tri` is the table in LDS or in global memory.
+// shade kernel's, in two steps: bounce_fetch requests what comes from memory (the triangle's normal,
+// its mesh's material: `tri` is the table in LDS or in global memory), bounce_apply computes -- the
+// fused kernel issues the fetches of all its packets in front of the wait for its prefix, so that
+// the shading loop behind it has no load in front of its stores (loads and stores share vmcnt).
 template <typename TriPtr>
-__device__ __forceinline__ void bounce_update(TriPtr tri, Rsrc mesh_r, const float4 *l_mat, float fsl_mult,
-                                              uint32_t ptri, float pt, F3 &o, F3 &d, float &a0, float &a1,
-                                              float &a2, float &a3, float &tau, float &nth)
+__device__ __forceinline__ void bounce_fetch(TriPtr tri, Rsrc mesh_r, uint32_t ptri, F3 &n, uint32_t &mat)
 {
     const float4 q2 = tri[HRT_ROW * ptri + 2];
-    const F3 n = {q2.y, q2.z, q2.w};
-    nth = incidence_angle(n, d);
+    n = {q2.y, q2.z, q2.w};
     const uint32_t mesh = __float_as_uint(tri[HRT_ROW * ptri + 4].w);
-    const uint32_t mat = ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
+    mat = ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
+}
+__device__ __forceinline__ void bounce_apply(const float4 *l_mat, float fsl_mult, F3 n, uint32_t mat, float pt, F3 &o,
+                                             F3 &d, float &a0, float &a1, float &a2, float &a3, float &tau, float &nth)
+{
+    nth = incidence_angle(n, d);
     float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
     float fsl = fsl_mult * pt;
     fsl *= fsl;
@@ -2307,6 +2312,22 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     HRT_PHASE(11);
     // ---- (4) survivors of all earlier macro-chunks, (5) the bounce itself (:616-659) and the stores ----
     if (do_trace) {
+        // Later launches: what the shading reads from memory -- the hit triangle's normal and material --
+        // is requested HERE, in front of the wait, so that the shading loop behind it has no load in
+        // front of its stores (C4 launch 1: 0.345 -> 0.329 ms).  Launch 0 keeps its registers instead
+        // (7 waves per SIMD): it reads the launch ray AGAIN inside the loop (id and direction were not
+        // kept through the traces; the lines were touched a few us ago: L2 / MALL hits) -- hoisting
+        // those K * 12 registers in front of the wait spills and costs more than it hides (0.309 -> 0.355).
+        F3 nk[K];
+        uint32_t matk[K];
+        if constexpr (!FIRST) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                nk[k] = {0.f, 0.f, 1.f};
+                matk[k] = 0u;
+                if (valid[k] && h[k].tri != HRT_NO_HIT) bounce_fetch(tri, mesh_r, h[k].tri, nk[k], matk[k]);
+            }
+        }
         if (tid < 64u) {   // wave 0
 #ifdef HRT_EXP_NOWAIT   /* timing experiment only: WRONG offsets */
             const uint32_t excl = chunk * MC / 2u;
@@ -2334,27 +2355,20 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
             const bool hit = valid[k] && h[k].tri != HRT_NO_HIT;
             if (hit) {
                 float nth = 0.f;
-                if (FIRST) {   // src/compute_paths.c:460-466 state init, :494-500 the launch Doppler term
-                    // ray id and direction are read AGAIN here (the lines were touched a few us ago: L2 /
-                    // MALL hits) instead of living in registers through the K traces: K * 5 registers less,
-                    // 7 waves per SIMD instead of 5 (C4 launch 0: 0.347 -> 0.309 ms)
+                if constexpr (FIRST) {   // src/compute_paths.c:460-466 state init, :494-500 the launch Doppler term
+                    // (issuing these loads one packet ahead of the stores -- loads and stores share vmcnt --
+                    // was measured too: 12 more registers, spills at 7 waves, 0.309 -> 0.34 ms on C4)
                     launch_entry(k);
                     const uint32_t tx = htri[k];
                     o[k] = tx_origin(k);
                     const F3 tv = {P.tx_vel[3 * tx], P.tx_vel[3 * tx + 1], P.tx_vel[3 * tx + 2]};
                     fs0[k] = dot3(tv, d[k]) * P.dop_mult;
+                    bounce_fetch(tri, mesh_r, h[k].tri, nk[k], matk[k]);
                 }
-#ifndef HRT_EXP_NOSHADE
-                bounce_update(tri, mesh_r, L.mat, P.fsl_mult, h[k].tri, h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k],
-                              tau[k], nth);
-#endif
+                bounce_apply(L.mat, P.fsl_mult, nk[k], matk[k], h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k], tau[k], nth);
                 const uint32_t k4 = (pos + before + lane_prefix(hm[k])) * 4u;
-#ifndef HRT_EXP_NOSTORE
                 store_survivor(hit_out(P, b), cap4, k4, ray[k], h[k].tri, nth, fs0[k], o[k], d[k], a0[k], a1[k], a2[k],
                                a3[k], tau[k]);
-#else
-                if (k4 == 0xfffffff0u) stf(hit_out(P, b), 0u, 0u, nth + o[k].x + d[k].y + a0[k] + tau[k]);
-#endif
             }
             pos += sub;
         }
