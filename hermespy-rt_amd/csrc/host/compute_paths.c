@@ -27,6 +27,7 @@
 
 #include <pthread.h>
 #include <unistd.h>
+#include <math.h>
 
 /* (the parallel-for of the host writers, hrt_parallel_ranges, and hrt_host_threads: parallel.c) */
 
@@ -113,6 +114,7 @@ static void work_free(work_t *w)
     hrt_hip_host_free(w->ray); hrt_hip_host_free(w->tri); hrt_hip_host_free(w->fs0);
     hrt_hip_host_free(w->ray2); hrt_hip_host_free(w->tri2); hrt_hip_host_free(w->fs02);
     for (int k = 0; k < 6; ++k) hrt_hip_host_free(w->st[k]);
+    for (int k = 0; k < 4; ++k) { hrt_hip_host_free(w->hs[k]); hrt_hip_host_free(w->hs2[k]); }
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec[k]);
     hrt_hip_host_free(w->mask);
     for (int k = 0; k < HRT_REC_FIELDS; ++k) hrt_hip_host_free(w->rec2[k]);
@@ -132,6 +134,12 @@ typedef struct {
     ChannelInfo *scat;
     uint64_t n_loc, i_base;   /* the range handed to scatter_range is relative to i_base */
     size_t rx, b, ntx, nb, np, amp_stride;
+    /* slim records: directions_rx and tau are not copied from the device (16 of a record's 36 bytes)
+     * but formed here from the hit's origin and delay (16 bytes per HIT) with the reference's own
+     * float sequence (src/compute_paths.c:676-678, :709): sub, mul, add, sqrtf, div -- IEEE
+     * operations, contraction off: the same bits as the device's */
+    const float *hs[4];       /* NULL: the records carry them */
+    float rxp[3];
     uint64_t unblocked[HRT_MAX_SCATTER_THREADS];
 } scatter_ctx;
 
@@ -157,6 +165,8 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     const float *r0 = c->rec[HRT_REC_A_TE_RE], *r1 = c->rec[HRT_REC_A_TE_IM], *r2 = c->rec[HRT_REC_A_TM_RE],
                 *r3 = c->rec[HRT_REC_A_TM_IM], *r4 = c->rec[HRT_REC_TAU], *r5 = c->rec[HRT_REC_DIRX],
                 *r6 = c->rec[HRT_REC_DIRY], *r7 = c->rec[HRT_REC_DIRZ], *r8 = c->rec[HRT_REC_DFS];
+    const float *const hox = c->hs[0], *const hoy = c->hs[1], *const hoz = c->hs[2], *const htau = c->hs[3];
+    const float rxx = c->rxp[0], rxy = c->rxp[1], rxz = c->rxp[2];
     /* The slots of consecutive records are scattered over a window of the dense arrays (the launch
      * order walks a z-band of 32 768 paths by azimuth, not by path index: 128 KB per array, seven
      * arrays): most stores miss the near caches, so the lines of the record HRT_SCATTER_AHEAD entries
@@ -191,8 +201,23 @@ static void scatter_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
         a1[off * as] = r1[i];
         a2[off * as] = r2[i];
         a3[off * as] = r3[i];
+        const int unblocked = (int)((c->mask[i >> 6] >> (i & 63)) & 1u);
+        if (hox) {
+            if (unblocked) {   /* :676-678 shadow direction and distance, :709 delay, :707 direction */
+                const float wx = rxx - hox[i], wy = rxy - hoy[i], wz = rxz - hoz[i];
+                const float d2rx = sqrtf((wx * wx + wy * wy) + wz * wz);
+                const float ux = wx / d2rx, uy = wy / d2rx, uz = wz / d2rx;
+                tau[off] = htau[i] + d2rx / HRT_C_F;
+                drx[off] = (Vec3){-ux, -uy, -uz};
+                fs[off] -= r8[i];       /* :722 */
+                ++unb;
+            } else {
+                tau[off] = 0.f;         /* :688 */
+            }
+            continue;
+        }
         tau[off] = r4[i];
-        if ((c->mask[i >> 6] >> (i & 63)) & 1u) {
+        if (unblocked) {
             drx[off] = (Vec3){r5[i], r6[i], r7[i]};
             fs[off] -= r8[i];       /* :722 */
             ++unb;
@@ -371,6 +396,10 @@ int hrt_worker_alloc(dev_ctx *c)
     ok &= hrt_hip_host_malloc((void **)&w->fs0, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask, cap / 64 * 8 + 8) == 0;
     for (int k = 0; k < 6 && with_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w->st[k], cap * 4) == 0;
+    for (int k = 0; k < 4; ++k) {
+        ok &= hrt_hip_host_malloc((void **)&w->hs[k], cap * 4) == 0;
+        ok &= hrt_hip_host_malloc((void **)&w->hs2[k], cap * 4) == 0;
+    }
     for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w->rec[k], cap * 4) == 0;
     for (int k = 0; k < HRT_REC_FIELDS; ++k) ok &= hrt_hip_host_malloc((void **)&w->rec2[k], cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask2, cap / 64 * 8 + 8) == 0;
@@ -389,7 +418,7 @@ void hrt_worker_release(dev_ctx *c)
     free(w->cur_rays); w->cur_rays = NULL;
     free(w->active); free(w->next_active); w->active = w->next_active = NULL;
     free(w->dirs_batch); w->dirs_batch = NULL;
-    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (5 + 2 * HRT_REC_FIELDS + 6);
+    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (5 + 2 * HRT_REC_FIELDS + 6 + 8);
     if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 24ull << 30)) {
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
         if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);
@@ -513,6 +542,9 @@ static int run_batch(dev_ctx *c, uint32_t g)
      * written: its rays and triangles and its first record block are requested then (`pre`), so no
      * copy is waited for with the writer idle except the very first. */
     const int can_pre = (ntx == 1) && !scat_rays && !env_int("HRT_NO_BOUNCE_PREFETCH", 0);
+    /* slim records (default; HRT_FULL_RECORDS=1 copies all nine fields): see scatter_ctx */
+    const int slim = !env_int("HRT_FULL_RECORDS", 0);
+    static const int hs_field[4] = {HRT_HIT_OX, HRT_HIT_OY, HRT_HIT_OZ, HRT_HIT_TAU};
     int pre = 0, flip = 0;   /* staging set of a block: (slot + flip) & 1 */
     for (size_t b = 0; b < nb; ++b) {
         const uint64_t H = w->h_counts[b + 1];
@@ -522,12 +554,14 @@ static int run_batch(dev_ctx *c, uint32_t g)
         if (H && prefetched) {   /* requested during the previous bounce, into the second pair of arrays */
             uint32_t *t_ = w->ray; w->ray = w->ray2; w->ray2 = t_;
             t_ = w->tri; w->tri = w->tri2; w->tri2 = t_;
+            for (int k = 0; k < 4; ++k) { float *f_ = w->hs[k]; w->hs[k] = w->hs2[k]; w->hs2[k] = f_; }
             int e = hrt_hip_stream_sync(w->copy_stream);
             if (!e) e = hrt_hip_stream_sync(w->copy_stream2);
             if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
         } else if (H) {
             DL(w->ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
             DL(w->tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
+            for (int k = 0; k < 4 && slim; ++k) DL(w->hs[k], hb + (uint64_t)hs_field[k] * L.cap * 4, H * 4);
             if (scat_rays)
                 for (int k = 0; k < 6; ++k)
                     DL(w->st[k], hb + (uint64_t)(HRT_HIT_OX + k) * L.cap * 4, H * 4);
@@ -547,6 +581,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
         const uint64_t i0_ = (I0), n_ = (I1) - (I0), w0_ = (I0) / 64, w1_ = ((I1) + 63) / 64;         \
         int e_ = 0;                                                                                  \
         for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                              \
+            if (!(slim && k >= HRT_REC_TAU && k <= HRT_REC_DIRZ))   /* formed on the host from the hits */ \
             e_ = hrt_hip_d2h_async((SET_REC)[k] + i0_, (const uint8_t *)w->d_ws + rb_ + ((uint64_t)k * L.cap + i0_) * 4, n_ * 4, \
                                    (k & 1) ? w->copy_stream2 : w->copy_stream);                      \
         if (!e_)                                                                                     \
@@ -609,6 +644,9 @@ static int run_batch(dev_ctx *c, uint32_t g)
                     const uint64_t Hn = w->h_counts[b + 2], hbn = L.off_hits + (b + 1) * L.hit_block_bytes;
                     int e = hrt_hip_d2h_async(w->ray2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_RAY * L.cap * 4, Hn * 4, w->copy_stream);
                     if (!e) e = hrt_hip_d2h_async(w->tri2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_TRI * L.cap * 4, Hn * 4, w->copy_stream2);
+                    for (int k = 0; k < 4 && slim && !e; ++k)
+                        e = hrt_hip_d2h_async(w->hs2[k], (const uint8_t *)w->d_ws + hbn + (uint64_t)hs_field[k] * L.cap * 4, Hn * 4,
+                                              (k & 1) ? w->copy_stream2 : w->copy_stream);
                     if (e) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e); goto done; }
                     if (slot & 1) FETCH_RX(b + 1, 0, w->rec, w->mask, 0, Hn);
                     else FETCH_RX(b + 1, 0, w->rec2, w->mask2, 0, Hn);
@@ -622,6 +660,10 @@ static int run_batch(dev_ctx *c, uint32_t g)
                     sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
                     sc.amp_stride = c->amp_stride;
                     sc.i_base = r0;
+                    if (slim) {
+                        for (int k = 0; k < 4; ++k) sc.hs[k] = w->hs[k];
+                        sc.rxp[0] = rx_pos[rx].x; sc.rxp[1] = rx_pos[rx].y; sc.rxp[2] = rx_pos[rx].z;
+                    }
                     if (!env_int("HRT_DEBUG_NO_SCATTER", 0))   /* timing experiments: copies only */
                         hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
                     for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st->records_unblocked += sc.unblocked[t];

@@ -101,6 +101,8 @@ typedef struct {
     uint32_t *ray2, *tri2;  /* ... of the NEXT bounce, requested while the last block of this one is written */
     float *fs0, *fs02;      /* launch Doppler term of the hits (path-list writer), this bounce's and the next's */
     float *st[6];           /* o, d of the hits */
+    float *hs[4], *hs2[4];  /* origin and delay of the hits after the bounce (this bounce's / the next's): the dense
+                             * writer forms directions_rx and tau of the records from them */
     float *rec[HRT_REC_FIELDS];
     uint64_t *mask;
     float *rec2[HRT_REC_FIELDS];   /* second staging set: the copy of the next (bounce, rx) block */

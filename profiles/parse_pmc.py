@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Turn the two PMC passes of profiles/collect_pmc.sh into profiles/<tag>_pmc_*.csv (trimmed
-to our kernels) and profiles/pmc_traffic.json (corrected HBM bytes per launch of the bounce
-kernel), which bench.py reports as roofline.traffic for the same workload."""
+"""profiles/collect_all.sh <tag> <workload> -> profiles/<tag>_pmc_{fetch,write}_size_<workload>.csv (trimmed to
+our kernels), profiles/<tag>_pmc_wave_<workload>.csv, profiles/<tag>_bench_<workload>_kernel_stats.csv and
+profiles/pmc_traffic.json: corrected HBM bytes per launch, which bench.py reports as roofline.traffic
+for the same workload.  A launch = one hrt_fused_kernel dispatch, or an hrt_trace_kernel dispatch and
+the hrt_shade_kernel (+ re-sort kernels) behind it."""
 import csv
 import glob
+import hashlib
 import json
 import os
-import hashlib
+import re
+import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -15,32 +19,50 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 workload = sys.argv[2] if len(sys.argv) > 2 else "c3"
 TRUE_KIB = 131072.0   # bench.py --calibrate: 32 Mi floats read, 32 Mi floats written
 
+
+def newest(pattern):
+    # gpurun merges results into gpurun_out/ without deleting older ones: take the newest
+    return max(glob.glob(os.path.join(REPO, "gpurun_out", pattern)), key=os.path.getmtime)
+
+
+def kind(name):
+    if "hrt_fused_kernel" in name:
+        return "fused"
+    if "hrt_trace_kernel" in name:
+        return "trace"
+    if "hrt_shade_kernel" in name:
+        return "shade"
+    if "hrt_sort" in name or "radix" in name.lower():
+        return "sort"
+    return None
+
+
+def is_launch0(name):
+    m = re.search(r"hrt_fused_kernel<(\w+), (\d+), (\w+), (\d+)>", name)
+    return bool(m) and m.group(3) == "true"
+
+
+keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+        "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
 raw = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    # gpurun merges results into gpurun_out/ without deleting older ones: take the newest
-    f = max(glob.glob(os.path.join(REPO, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv")),
-            key=os.path.getmtime)
+    f = newest(os.path.join("pmc_%s_%s_%s" % (tag, workload, ctr), "*", "*counter_collection.csv"))
     rows = [r for r in csv.DictReader(open(f)) if "hrt_" in r["Kernel_Name"]]
-    keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
-            "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
     with open(os.path.join(HERE, "%s_pmc_%s_%s.csv" % (tag, ctr.lower(), workload)), "w", newline="") as fo:
         w = csv.DictWriter(fo, keep)
         w.writeheader()
         for r in rows:
             w.writerow({k: r[k] for k in keep})
     cal = [float(r["Counter_Value"]) for r in rows if "selftest" in r["Kernel_Name"]][0]
-    n_steps = len([r for r in rows if "los" in r["Kernel_Name"]])
-    # one "launch" of the bounce = trace kernel + shade kernel (+ the scan/move kernels of the
-    # stable compaction that follow it): sum their counters per trace-kernel dispatch
+    rows = [r for r in rows if kind(r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    n_steps = sum(1 for r in rows if is_launch0(r["Kernel_Name"])) or sum(1 for r in rows if "los" in r["Kernel_Name"])
     per, kinds = [], {}
     for r in rows:
-        n = r["Kernel_Name"]
-        if "selftest" in n or "los" in n or not any(t in n for t in ("trace_kernel", "shade_kernel", "scan", "move")):
-            continue   # (problem-creation kernels -- hrt_rxt_build_kernel -- are not part of a step)
-        if "trace" in n:
+        k = kind(r["Kernel_Name"])
+        if k in ("fused", "trace"):
             per.append(0.0)
         per[-1] += float(r["Counter_Value"])
-        k = "trace" if "trace" in n else "shade" if "shade" in n else "compaction"
         kinds[k] = kinds.get(k, 0.0) + float(r["Counter_Value"]) / n_steps
     per_step = len(per) // n_steps
     raw[ctr] = dict(corr=TRUE_KIB / cal, per_launch=[sum(per[i::per_step]) / n_steps for i in range(per_step)],
@@ -51,11 +73,11 @@ write = [x * raw["WRITE_SIZE"]["corr"] * 1024 for x in raw["WRITE_SIZE"]["per_la
 path = os.path.join(HERE, "pmc_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[workload] = dict(
-    kernels_sha16=hashlib.sha256(open(os.path.join(REPO, 'hermespy-rt_amd', 'csrc', 'hrt_kernels.hip'), 'rb').read()).hexdigest()[:16],
-    n_gpus=1, kernel="hrt_trace_kernel + hrt_shade_kernel (+ scan/move of the compaction)", round=tag,
+    kernels_sha16=hashlib.sha256(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", "hrt_kernels.hip"), "rb").read()).hexdigest()[:16],
+    n_gpus=1, kernel="per launch: hrt_fused_kernel, or hrt_trace_kernel + hrt_shade_kernel", round=tag,
     by_kernel_bytes_per_step={k: dict(fetch=raw["FETCH_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["FETCH_SIZE"]["corr"] * 1024,
                                       write=raw["WRITE_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["WRITE_SIZE"]["corr"] * 1024)
-                              for k in ("trace", "shade", "compaction")},
+                              for k in ("fused", "trace", "shade", "sort")},
     source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/%s_pmc_*_%s.csv); "
            "KiB counters, calibrated on a known-traffic launch of the same access pattern: "
            "FETCH_SIZE x%.3f (gfx950 half-count), WRITE_SIZE x%.3f" % (tag, workload, raw["FETCH_SIZE"]["corr"], raw["WRITE_SIZE"]["corr"]),
@@ -63,3 +85,17 @@ allj[workload] = dict(
     hbm_bytes_per_step=sum(fetch) + sum(write), hbm_bytes_per_launch_avg=(sum(fetch) + sum(write)) / len(fetch))
 json.dump(allj, open(path, "w"), indent=1)
 print(json.dumps(allj[workload], indent=1))
+
+# wave-state counters, trimmed; kernel stats of the --stats run
+try:
+    f = newest(os.path.join("pmc_%s_%s_WAVE" % (tag, workload), "*", "*counter_collection.csv"))
+    rows = [r for r in csv.DictReader(open(f)) if kind(r["Kernel_Name"])]
+    with open(os.path.join(HERE, "%s_pmc_wave_%s.csv" % (tag, workload)), "w", newline="") as fo:
+        w = csv.DictWriter(fo, ["Dispatch_Id", "Grid_Size", "Kernel_Name", "VGPR_Count", "Counter_Name", "Counter_Value"])
+        w.writeheader()
+        for r in rows:
+            w.writerow({k: r[k] for k in w.fieldnames})
+    f = newest(os.path.join("prof_%s_%s" % (tag, workload), "*", "*kernel_stats.csv"))
+    shutil.copy(f, os.path.join(HERE, "%s_bench_%s_kernel_stats.csv" % (tag, workload)))
+except ValueError as e:
+    print("no wave / stats pass found:", e)
