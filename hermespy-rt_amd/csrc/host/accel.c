@@ -206,6 +206,12 @@ static int canon_key(const float *n, uint32_t *key, double c[3])
 }
 
 /* rows: the table ALREADY in its final (Morton) order */
+static int cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
 int hrt_accel_build(hrt_accel *a, const float *rows)
 {
     const uint32_t T = a->num_tri;
@@ -268,10 +274,8 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
                 }
             }
             if (n) {
-                /* median by partial selection: nl is small (T / 64) */
-                for (uint32_t i = 0; i <= n / 2; ++i)
-                    for (uint32_t j = i + 1; j < n; ++j)
-                        if (rad[j] < rad[i]) { const float t = rad[i]; rad[i] = rad[j]; rad[j] = t; }
+                /* median (nl = T / 64 can be 2.6e5 at 16 M triangles: a sort, not a selection in O(nl^2)) */
+                qsort(rad, n, sizeof(float), cmp_float);
                 const double ext = 0.5 * sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
                                               (hi[2] - lo[2]) * (hi[2] - lo[2]));
                 a->big = (double)rad[n / 2] < ratio * ext;
@@ -314,7 +318,12 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
             ++k;
         }
         free(c64);
-        if (nb > 64u) return hrt_fail(HRT_E_CAPACITY, "too many triangles for the acceleration structure");
+        if (nb > 64u) {   /* more than 64^4 triangles: no trees, the leaves are walked (any table size) */
+            for (uint32_t q = 0; q < HRT_ACCEL_MAX_LEVELS; ++q) { free(a->node[q]); a->node[q] = NULL; a->node_count[q] = 0; }
+            a->num_levels = 0;
+            a->big = 0;
+            return HRT_OK;
+        }
         a->num_levels = k;
     }
 
@@ -400,7 +409,18 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
         }
         a->pl_levels = k;
         free(ks); free(cn);
-        if (a->pl_count[k - 1] > 64u) return hrt_fail(HRT_E_CAPACITY, "too many triangles for the plane tree");
+        if (a->pl_count[k - 1] > 64u) {
+            /* more than 64^4 triangles in a sparse scene: the trees do not fit their levels -- drop them
+             * and walk the leaves (any table size) instead of failing the problem */
+            for (uint32_t q = 0; q < HRT_ACCEL_MAX_LEVELS; ++q) {
+                free(a->node[q]); a->node[q] = NULL; a->node_count[q] = 0;
+                free(a->pl_node[q]); a->pl_node[q] = NULL; a->pl_count[q] = 0;
+            }
+            free(a->pl_index); a->pl_index = NULL;
+            free(a->pl_rec); a->pl_rec = NULL;
+            a->num_levels = 0; a->pl_levels = 0; a->pl_num_leaf = 0;
+            a->big = 0;
+        }
     }
     return HRT_OK;
 }

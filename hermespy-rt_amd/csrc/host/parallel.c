@@ -8,6 +8,7 @@
 #include "hrt_internal.h"
 
 #include <pthread.h>
+#include <sys/types.h>
 #include <unistd.h>
 
 /* The dense scatter is host-memory bound and every record owns its slots, so it splits into
@@ -29,6 +30,8 @@ struct range_pool {
     uint64_t gen;                        /* job number: a helper runs each job once */
     int pending, stop;
     range_fn fn; void *ctx; uint64_t n; int parts;
+    pid_t owner;                         /* the process that created the helpers: a fork()ed child inherits the
+                                          * struct but none of the threads, and must not wait for them */
 };
 static pthread_key_t g_pool_key;
 static pthread_once_t g_pool_once = PTHREAD_ONCE_INIT;
@@ -77,12 +80,22 @@ static range_pool *pool_get(int helpers)
 {
     pthread_once(&g_pool_once, pool_key_make);
     range_pool *p = (range_pool *)pthread_getspecific(g_pool_key);
+    if (p && p->owner != getpid()) {
+        /* after fork(): the parent's helpers do not exist here.  The inherited pool is dropped without
+         * joining (its mutex / condition variables may be in any state: leaked, a few hundred bytes) and
+         * a fresh one is made */
+        pthread_setspecific(g_pool_key, NULL);
+        p = NULL;
+    }
     if (!p) {
         p = (range_pool *)calloc(1, sizeof *p);
         if (!p) return NULL;
-        pthread_mutex_init(&p->mu, NULL);
-        pthread_cond_init(&p->cv_start, NULL);
-        pthread_cond_init(&p->cv_done, NULL);
+        p->owner = getpid();
+        if (pthread_mutex_init(&p->mu, NULL) != 0) { free(p); return NULL; }
+        if (pthread_cond_init(&p->cv_start, NULL) != 0) { pthread_mutex_destroy(&p->mu); free(p); return NULL; }
+        if (pthread_cond_init(&p->cv_done, NULL) != 0) {
+            pthread_cond_destroy(&p->cv_start); pthread_mutex_destroy(&p->mu); free(p); return NULL;
+        }
         if (pthread_setspecific(g_pool_key, p) != 0) { pool_destroy(p); return NULL; }
     }
     while (p->n_workers < helpers && p->n_workers < HRT_MAX_SCATTER_THREADS - 1) {
@@ -133,5 +146,8 @@ void hrt_parallel_release(void)
 {
     pthread_once(&g_pool_once, pool_key_make);
     range_pool *p = (range_pool *)pthread_getspecific(g_pool_key);
-    if (p) { pthread_setspecific(g_pool_key, NULL); pool_destroy(p); }
+    if (p) {
+        pthread_setspecific(g_pool_key, NULL);
+        if (p->owner == getpid()) pool_destroy(p);   /* (a fork()ed child has no helpers to join) */
+    }
 }

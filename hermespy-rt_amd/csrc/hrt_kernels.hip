@@ -3009,13 +3009,11 @@ int hrt_hip_launch_order(const uint32_t *d_seg_start, const uint32_t *d_seg_band
                          uint32_t *d_order, void *stream)
 {
     if (num_seg == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per launch: the attribute is per device, and with HRT_DEVICES one host thread per device comes here
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hrt_launch_order_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)(HRT_ORDER_SEG * 4u));
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(hrt_launch_order_kernel, dim3(num_seg), dim3(1024), HRT_ORDER_SEG * 4u,
                        (hipStream_t)stream, d_seg_start, d_seg_band, num_paths, rank, count, chunk, d_order);

@@ -123,3 +123,17 @@ def test_complex_amplitudes_written_in_place(rt, product_lib, name, monkeypatch)
             assert np.array_equal(g.imag.view(np.uint32), im.reshape(-1).view(np.uint32)), (blk, pol, "im")
         tau = np.where(abi.written(ref[blk]["tau"]), ref[blk]["tau"], np.float32(0)).astype(np.float32)
         assert np.array_equal(np.ascontiguousarray(got.tau).reshape(-1).view(np.uint32), tau.reshape(-1).view(np.uint32))
+
+
+def test_cache_clear_is_exposed_and_calls_still_work(rt):
+    """hermespy_rt.cache_clear() releases the buffers kept between calls; the next
+    call allocates again and returns the same values."""
+    c = K.small(K.C1, 2000)
+    args = (c["scene_path"], np.array(c["rx_pos"], np.float32), np.array(c["tx_pos"], np.float32),
+            np.array(c["rx_vel"], np.float32), np.array(c["tx_vel"], np.float32), c["f_ghz"], 1, 1, 2000, 1)
+    a = rt.compute_paths(*args)[1]
+    rt.cache_clear()
+    rt.cache_clear()          # nothing kept: a no-op
+    b = rt.compute_paths(*args)[1]
+    assert np.array_equal(a.tau.view(np.uint32), b.tau.view(np.uint32))
+    assert np.array_equal(a.a_te.view(np.uint32), b.a_te.view(np.uint32))
