@@ -41,8 +41,6 @@
 //   * No MFMA: this is branchy intersection, not a contraction.
 #include <hip/hip_runtime.h>
 #include <string.h>
-#include <rocprim/device/device_radix_sort.hpp>   // radix sort of the re-sort keys (a library primitive; the
-                                // key and permutation kernels around it are below)
 
 #include <stdint.h>
 #include <stdio.h>
@@ -2590,10 +2588,10 @@ __global__ __launch_bounds__(64) void hrt_rxt_build_kernel(const float *tri_f, u
 }
 
 // ===================================================================================
-// Re-sort of the survivors of bounce b (hrt_ksort): keys, then (rocPRIM, in the shim) a stable
-// radix sort of (key, index), then the permutation of the 15 field arrays from the scratch block
-// into hit block b.  The number of survivors is only known on the device (counts[b + 1]); entries
-// beyond it get the largest key and are not moved.
+// Re-sort of the survivors of bounce b (hrt_ksort): keys, then a stable radix sort of (key, index)
+// (the kernels below), then the permutation of the 15 field arrays from the scratch block into hit
+// block b.  The number of survivors is only known on the device (counts[b + 1]): every kernel is
+// launched over the block's capacity and works on the survivors only.
 // ===================================================================================
 __device__ __forceinline__ uint32_t spread5(uint32_t v)   // 5 bits -> every third bit
 {
@@ -2613,7 +2611,8 @@ __global__ void hrt_sort_keys_kernel(const hrt_kparams P, const uint32_t b)
     uint32_t *keys = reinterpret_cast<uint32_t *>(P.ws + P.sort.off_keys);
     uint32_t *idx = keys + 2u * P.cap;
     uint32_t key = 0xffffffffu;
-    if (i < n) {
+    if (i >= n) return;   // the sort's size is the survivor count
+    {
         const uint32_t cap4 = (uint32_t)P.cap * 4u, i4 = i * 4u;
         const Rsrc r = make_rsrc(P.ws + P.sort.off_scratch);
         const uint32_t ray = ldu(r, H_RAY * cap4, i4);
@@ -2661,12 +2660,168 @@ __global__ void hrt_sort_keys_kernel(const hrt_kparams P, const uint32_t b)
     idx[i] = i;
 }
 
-__global__ void hrt_sort_permute_kernel(const hrt_kparams P, const uint32_t b)
+// ---- the sort itself: a stable LSD radix sort of (key, index) pairs whose SIZE is the survivor
+// count on the device (counts[b + 1]) -- launched over the block's capacity, workgroups past the
+// count leave at once.  Digits of up to 11 bits: the usual 20-bit key is two passes.  Per pass three
+// kernels over tiles of kSortTile pairs:
+//   hist     per tile the histogram of the pass's digit            -> hist[digit][tile]
+//   scan     per digit (one workgroup each) the exclusive scan over the tiles, in place, and the
+//            digit's total                                          -> hist[digit][tile], total[digit]
+//   scatter  per tile: offsets of the digits from the totals, and every pair to
+//            base(digit) + hist[digit][tile] + (its rank among the tile's pairs of that digit)
+// The rank is found without a local sort: the four waves of a workgroup take the four quarters of
+// the tile, a wave walks its quarter 64 pairs at a time, the lanes with the same digit find each
+// other with one ballot per digit bit, rank = pairs of that digit earlier in the quarter + lanes of
+// the match mask below one's own -- order of arrival kept, so every pass is stable.
+// Buffers (hrt_ksort.off_keys): keys A, keys B, index A, index B (cap words each); pass p reads
+// A/B by parity.  hist: kSortBins x tiles words at hrt_ksort.off_tmp, the kSortBins totals behind.
+constexpr uint32_t kSortTile = 2048u, kSortBins = 2048u;
+
+struct SortArgs {
+    uint32_t *key_a, *key_b, *idx_a, *idx_b, *hist, *total;
+    const uint32_t *count;   // counts[b + 1]
+    uint32_t tiles_max, shift, bits, parity;
+};
+
+__global__ __launch_bounds__(256) void hrt_sort_hist_kernel(const SortArgs A)
+{
+    __shared__ uint32_t h[kSortBins];
+    const uint32_t n = *A.count, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t i0 = tile * kSortTile, bins = 1u << A.bits, dmask = bins - 1u;
+    if (i0 >= n) return;
+    const uint32_t *keys = A.parity ? A.key_b : A.key_a;
+    for (uint32_t d = tid; d < bins; d += 256u) h[d] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < kSortTile / 256u; ++r) {
+        const uint32_t i = i0 + r * 256u + tid;
+        if (i < n) atomicAdd(&h[(keys[i] >> A.shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < bins; d += 256u) A.hist[d * A.tiles_max + tile] = h[d];
+}
+
+// inclusive scan of x over the workgroup's threads in thread order; `all` = the total
+template <uint32_t WAVES>
+__device__ __forceinline__ uint32_t block_scan_incl(uint32_t x, uint32_t *part, uint32_t tid, uint32_t &all)
+{
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if ((int)lane >= d) x += y;
+    }
+    __syncthreads();   // (part may still be read from the previous call)
+    if (lane == 63u) part[wave] = x;
+    __syncthreads();
+    uint32_t before = 0u;
+    all = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) {
+        const uint32_t pw = part[w];
+        before += w < wave ? pw : 0u;
+        all += pw;
+    }
+    return before + x;
+}
+
+// one workgroup per digit: exclusive scan of hist[digit][0 .. tiles) in place, total[digit]
+__global__ __launch_bounds__(1024) void hrt_sort_scan_kernel(const SortArgs A)
+{
+    __shared__ uint32_t part[16];
+    const uint32_t n = *A.count, tid = threadIdx.x;
+    const uint32_t tiles = (n + kSortTile - 1u) / kSortTile;
+    uint32_t *row = A.hist + blockIdx.x * A.tiles_max;
+    uint32_t carry = 0u;
+    for (uint32_t base = 0; base < tiles; base += 1024u) {   // (uniform trip count)
+        const uint32_t t = base + tid;
+        const uint32_t v = t < tiles ? row[t] : 0u;
+        uint32_t all;
+        const uint32_t incl = block_scan_incl<16>(v, part, tid, all);
+        if (t < tiles) row[t] = carry + incl - v;
+        carry += all;
+    }
+    if (tid == 0) A.total[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void hrt_sort_scatter_kernel(const SortArgs A)
+{
+    __shared__ uint32_t base[kSortBins], cnt[4][kSortBins], part[4];
+    const uint32_t n = *A.count, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t i0 = tile * kSortTile, bins = 1u << A.bits, dmask = bins - 1u;
+    if (i0 >= n) return;
+    const uint32_t *kin = A.parity ? A.key_b : A.key_a, *iin = A.parity ? A.idx_b : A.idx_a;
+    uint32_t *kout = A.parity ? A.key_a : A.key_b, *iout = A.parity ? A.idx_a : A.idx_b;
+    // base[d] = pairs with a smaller digit (exclusive scan of the totals) + this tile's offset in d;
+    // thread t owns the digits 8 t .. 8 t + 7
+    {
+        uint32_t v[8], sum = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t d = tid * 8u + j;
+            v[j] = d < bins ? A.total[d] : 0u;
+            sum += v[j];
+        }
+        uint32_t all;
+        uint32_t run = block_scan_incl<4>(sum, part, tid, all) - sum;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t d = tid * 8u + j;
+            if (d < bins) base[d] = run + A.hist[d * A.tiles_max + tile];
+            run += v[j];
+        }
+        for (uint32_t d = tid; d < bins; d += 256u) { cnt[0][d] = 0u; cnt[1][d] = 0u; cnt[2][d] = 0u; cnt[3][d] = 0u; }
+    }
+    __syncthreads();
+    // the wave's quarter of the tile: count its digits, then the quarters in front of it
+    constexpr uint32_t Q = kSortTile / 4u;
+    const uint32_t q0 = i0 + wave * Q;
+    uint32_t key[Q / 64u], idx[Q / 64u];
+#pragma unroll
+    for (uint32_t r = 0; r < Q / 64u; ++r) {
+        const uint32_t i = q0 + r * 64u + lane;
+        key[r] = i < n ? kin[i] : 0u;
+        idx[r] = i < n ? iin[i] : 0u;
+        if (i < n) atomicAdd(&cnt[wave][(key[r] >> A.shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < bins; d += 256u) {
+        // cnt[w][d] becomes: pairs of digit d in the quarters in front of quarter w (running counter of wave w)
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
+        cnt[0][d] = 0u; cnt[1][d] = c0; cnt[2][d] = c0 + c1; cnt[3][d] = c0 + c1 + c2;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t r = 0; r < Q / 64u; ++r) {
+        const uint32_t i = q0 + r * 64u + lane;
+        const bool have = i < n;
+        const uint32_t d = (key[r] >> A.shift) & dmask;
+        unsigned long long m = HRT_BALLOT(have);
+        for (uint32_t bit = 0; bit < A.bits; ++bit) {
+            const unsigned long long bb = HRT_BALLOT((d >> bit) & 1u);
+            m &= ((d >> bit) & 1u) ? bb : ~bb;
+        }
+        // (m: the lanes of this round with my digit; all lanes of a match group read the counter before
+        // its leader bumps it: same wave, program order)
+        uint32_t at = 0u;
+        if (have) at = cnt[wave][d];
+        const uint32_t rank = (uint32_t)__popcll(m & lt);
+        if (have && rank == 0u) cnt[wave][d] = at + (uint32_t)__popcll(m);
+        if (have) {
+            const uint32_t dst = base[d] + at + rank;
+            kout[dst] = key[r];
+            iout[dst] = idx[r];
+        }
+    }
+}
+
+// moves the 15 field arrays of the survivors from the scratch block into hit block b, in sorted order
+__global__ void hrt_sort_permute_kernel(const hrt_kparams P, const uint32_t b, const uint32_t *perm)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
     if (i >= counts[b + 1]) return;
-    const uint32_t *perm = reinterpret_cast<const uint32_t *>(P.ws + P.sort.off_keys) + 3u * P.cap;   // sorted index
     const uint32_t src4 = perm[i] * 4u, dst4 = i * 4u, cap4 = (uint32_t)P.cap * 4u;
     const Rsrc in = make_rsrc(P.ws + P.sort.off_scratch), out = hit_blk(P, b);
 #pragma unroll
@@ -2967,10 +3122,8 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
 
 uint64_t hrt_hip_sort_temp_bytes(uint64_t cap)
 {
-    size_t bytes = 0;
-    uint32_t *null = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, null, null, null, null, (size_t)cap, 0u, 32u, (hipStream_t) nullptr);
-    return (uint64_t)bytes;
+    const uint64_t tiles = (cap + kSortTile - 1u) / kSortTile;
+    return ((uint64_t)kSortBins * tiles + kSortBins) * 4u;   // hist[bins][tiles] + total[bins]
 }
 
 int hrt_hip_sort_hits(const hrt_kparams *P, uint32_t bounce, void *stream)
@@ -2979,11 +3132,28 @@ int hrt_hip_sort_hits(const hrt_kparams *P, uint32_t bounce, void *stream)
     const uint32_t blocks = (uint32_t)((P->cap + 255) / 256);
     hipLaunchKernelGGL(hrt_sort_keys_kernel, dim3(blocks), dim3(256), 0, st, *P, bounce);
     uint32_t *keys = reinterpret_cast<uint32_t *>(P->ws + P->sort.off_keys);
-    size_t tmp = (size_t)P->sort.tmp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(P->ws + P->sort.off_tmp, tmp, keys, keys + P->cap, keys + 2 * P->cap,
-                                             keys + 3 * P->cap, (size_t)P->cap, 0u, P->sort.key_bits, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(hrt_sort_permute_kernel, dim3(blocks), dim3(256), 0, st, *P, bounce);
+    SortArgs A;
+    A.key_a = keys; A.key_b = keys + P->cap; A.idx_a = keys + 2 * P->cap; A.idx_b = keys + 3 * P->cap;
+    A.tiles_max = (uint32_t)((P->cap + kSortTile - 1u) / kSortTile);
+    A.hist = reinterpret_cast<uint32_t *>(P->ws + P->sort.off_tmp);
+    A.total = A.hist + (uint64_t)kSortBins * A.tiles_max;
+    A.count = reinterpret_cast<const uint32_t *>(P->ws + P->off_counts) + bounce + 1u;
+    if (((uint64_t)kSortBins * A.tiles_max + kSortBins) * 4u > P->sort.tmp_bytes) return (int)hipErrorInvalidValue;
+    // digits of up to 11 bits: 2 passes up to 22 key bits (the usual key has 20), 3 beyond
+    const uint32_t kb = P->sort.key_bits ? P->sort.key_bits : 1u;
+    const uint32_t passes = kb <= 11u ? 1u : (kb <= 22u ? 2u : 3u);
+    const uint32_t bits = (kb + passes - 1u) / passes;
+    for (uint32_t p = 0; p < passes; ++p) {
+        A.shift = bits * p;
+        A.bits = bits;
+        A.parity = p & 1u;
+        hipLaunchKernelGGL(hrt_sort_hist_kernel, dim3(A.tiles_max), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(hrt_sort_scan_kernel, dim3(1u << bits), dim3(1024), 0, st, A);
+        hipLaunchKernelGGL(hrt_sort_scatter_kernel, dim3(A.tiles_max), dim3(256), 0, st, A);
+    }
+    // the sorted indices: buffer B after an odd number of passes, A after an even one
+    hipLaunchKernelGGL(hrt_sort_permute_kernel, dim3(blocks), dim3(256), 0, st, *P, bounce,
+                       (const uint32_t *)((passes & 1u) ? A.idx_b : A.idx_a));
     return (int)hipGetLastError();
 }
 

@@ -102,7 +102,7 @@ typedef struct {
     float lo[3], inv_cell[3];       /* cell = (o - lo) * inv_cell */
     uint64_t off_scratch;           /* workspace: a hit-block-sized scratch */
     uint64_t off_keys;              /* workspace: 4 arrays of cap u32 (keys in/out, index in/out) */
-    uint64_t off_tmp, tmp_bytes;    /* workspace: rocPRIM temporary storage */
+    uint64_t off_tmp, tmp_bytes;    /* workspace: digit histograms of the radix sort ([256][tiles] + 256 totals) */
 } hrt_ksort;
 
 typedef struct {
