@@ -1599,9 +1599,16 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
 // LDS: [17*4 float4 materials][num_rx float4 RX pos][4 u32 wave counts][4 u32 wave sums]
 // ===================================================================================
 #ifndef HRT_SHADE_WAVES
-#define HRT_SHADE_WAVES 5   /* an upper bound of 96 VGPRs; the kernel uses ~78: 6 waves/SIMD, no spills
-                             * (7 gains nothing, 8 spills and is 40 % slower) */
+#define HRT_SHADE_WAVES 6   /* at most 80 VGPRs: 6 waves/SIMD (5 is 7 % slower; 7 gains nothing, 8 spills and is
+                             * 40 % slower) */
 #endif
+// NLDS: the per-triangle normals (+ mesh ids) and the mesh rows are staged in LDS (tables of up to
+// kShadeLdsTri triangles / kShadeLdsMesh meshes): the record loop then reads nothing from global
+// memory between its stores except the shadow result words, which are requested four RXs at a time in
+// front of those RXs' records -- loads and stores share vmcnt in issue order, so a load behind a
+// record's nine stores waits for them to reach L2.
+constexpr uint32_t kShadeLdsTri = 2048u, kShadeLdsMesh = 256u;
+template <bool NLDS>
 __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(const hrt_kparams P,
                                                               const uint32_t b)
 {
@@ -1620,14 +1627,39 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     float4 *l_mat = lds;
     float4 *l_rx = l_mat + 4u * HRT_NUM_MATERIALS;
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(l_rx + P.num_rx);
+    float4 *l_trin = reinterpret_cast<float4 *>(l_wcnt + 8);   // [T]: n.xyz, mesh id (bits)
+    float4 *l_mesh = l_trin + P.num_tri;                         // [M]: velocity, material (bits)
     {
         const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
         for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) l_mat[k] = g_mat[k];
         for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
             l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
+        if constexpr (NLDS) {
+            for (uint32_t k = tid; k < P.num_tri; k += HRT_BLOCK) {
+                const float *row = P.tri + (size_t)k * HRT_TRI_FLOATS;
+                l_trin[k] = make_float4(row[9], row[10], row[11], row[19]);
+            }
+            const float4 *g_mesh = reinterpret_cast<const float4 *>(P.mesh);
+            for (uint32_t k = tid; k < P.num_mesh; k += HRT_BLOCK) l_mesh[k] = g_mesh[k];
+        }
     }
     __syncthreads();
     const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // normal and mesh id of table row j; row of the mesh table
+    auto tri_normal = [&](uint32_t j, uint32_t &mesh) -> F3 {
+        if constexpr (NLDS) {
+            const float4 q = l_trin[j];
+            mesh = __float_as_uint(q.w);
+            return {q.x, q.y, q.z};
+        } else {
+            mesh = ldu(tri_r, 0u, j * (HRT_TRI_FLOATS * 4u) + 76u);
+            return gather3(tri_r, HRT_TRI_FLOATS * 4u, j, 36u);
+        }
+    };
+    auto mesh_row = [&](uint32_t m) -> float4 {
+        if constexpr (NLDS) return l_mesh[m];
+        else return gather4(mesh_r, HRT_MESH_FLOATS * 4u, m, 0u);
+    };
 
     for (uint64_t base = (uint64_t)blockIdx.x * HRT_BLOCK; base < n_in;
          base += (uint64_t)gridDim.x * HRT_BLOCK) {
@@ -1665,76 +1697,102 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             }
         }
 
+        // the bounce's own trace result: requested in front of the records' stores
+        uint32_t ptri = HRT_NO_HIT;
+        float pt = 0.f;
+        if (do_trace && valid) {
+            ptri = ldu(res_blk(P, P.num_rx), 0u, i4);
+            pt = ldf(res_blk(P, P.num_rx), cap4, i4);
+        }
+
         // ---- scatter records of bounce b-1 ----
         if (!first) {
             const uint32_t pb = b - 1;
             F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
             float mat_s = 0.f, mat_alpha = 1.f;
             if (valid) {
-                n = gather3(tri_r, HRT_TRI_FLOATS * 4u, htri, 36u);
-                const uint32_t mesh = ldu(tri_r, 0u, htri * (HRT_TRI_FLOATS * 4u) + 76u);
-                const float4 mm = gather4(mesh_r, HRT_MESH_FLOATS * 4u, mesh, 0u);
+                uint32_t mesh;
+                n = tri_normal(htri, mesh);
+                const float4 mm = mesh_row(mesh);
                 mvel = {mm.x, mm.y, mm.z};
                 const float4 m3 = l_mat[4u * __float_as_uint(mm.w) + 3u];
                 mat_s = m3.x;
                 mat_alpha = m3.y;
             }
-            for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
-                bool unblocked = false;
-                if (valid) {
-                    const float4 rp = l_rx[rx];
-                    float d2rx;
-                    const F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
-                    uint32_t stri;   // the shadow result: see the trace kernel
-                    bool near1;
-                    if (P.num_tri < HRT_HALF_RESULTS_MAX) {
-                        const uint32_t code16 =
-                            (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(res_blk(P, rx), (int)(i * 2u), 0, 0);
-                        stri = code16 & 0x7fffu;
-                        near1 = (code16 >> 15) != 0u;
-                        if (stri == 0x7fffu) stri = HRT_NO_HIT;
-                    } else {
-                        const uint32_t code = ldu(res_blk(P, rx), 0u, i4);
-                        stri = code & 0x7fffffffu;
-                        near1 = (code >> 31) != 0u;
-                        if (stri == 0x7fffffffu) stri = HRT_NO_HIT;
-                    }
-                    if (stri != HRT_NO_HIT && stri >= P.num_tri) {   // cannot happen; never fault
-                        atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
-                        stri = HRT_NO_HIT;
-                    }
-                    if (stri != HRT_NO_HIT)
-                        theta = incidence_angle(gather3(tri_r, HRT_TRI_FLOATS * 4u, stri, 36u), w);
-                    if (stri != HRT_NO_HIT && near1) {
-                        stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, 0.f);
-                        stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, 0.f);
-                        stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, 0.f);
-                        stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, 0.f);
-                        stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, 0.f);
-                    } else {
-                        unblocked = true;
-                        const float th_s = acos_f_ool(dot3(w, n));
-                        const float4 S = scatter_pattern(mat_s, mat_alpha, th_s, theta);
-                        float o0 = a0 * S.x - a1 * S.y;
-                        float o1 = a0 * S.y + a1 * S.x;
-                        float o2 = a2 * S.z - a3 * S.w;
-                        float o3 = a2 * S.w + a3 * S.z;
-                        float f2 = P.fsl_mult * d2rx;
-                        f2 *= f2;
-                        if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
-                        stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, o0);
-                        stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, o1);
-                        stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, o2);
-                        stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, o3);
-                        stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, tau + d2rx / kC);
-                        stf(rec_blk(P, pb, rx), R_DX * cap4, i4, -w.x);
-                        stf(rec_blk(P, pb, rx), R_DY * cap4, i4, -w.y);
-                        stf(rec_blk(P, pb, rx), R_DZ * cap4, i4, -w.z);
-                        stf(rec_blk(P, pb, rx), R_DFS * cap4, i4, dot3(sub3(w, d), mvel) * P.dop_mult);
+            for (uint32_t rx0 = 0; rx0 < P.num_rx; rx0 += 4u) {
+                // the shadow results of four RXs (see the trace kernel): one word or half word each
+                uint32_t code[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    code[j] = 0u;
+                    if (valid && rx0 + j < P.num_rx) {
+                        if (P.num_tri < HRT_HALF_RESULTS_MAX)
+                            code[j] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(res_blk(P, rx0 + j), (int)(i * 2u), 0, 0);
+                        else
+                            code[j] = ldu(res_blk(P, rx0 + j), 0u, i4);
                     }
                 }
-                const unsigned long long m = __ballot(unblocked);
-                if (lane == 0 && valid) mask_words(P, pb, rx)[i >> 6] = m;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const uint32_t rx = rx0 + j;
+                    if (rx >= P.num_rx) break;   // wave-uniform
+                    bool unblocked = false;
+                    if (valid) {
+                        const float4 rp = l_rx[rx];
+                        float d2rx;
+                        const F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
+                        uint32_t stri;
+                        bool near1;
+                        if (P.num_tri < HRT_HALF_RESULTS_MAX) {
+                            stri = code[j] & 0x7fffu;
+                            near1 = (code[j] >> 15) != 0u;
+                            if (stri == 0x7fffu) stri = HRT_NO_HIT;
+                        } else {
+                            stri = code[j] & 0x7fffffffu;
+                            near1 = (code[j] >> 31) != 0u;
+                            if (stri == 0x7fffffffu) stri = HRT_NO_HIT;
+                        }
+                        if (stri != HRT_NO_HIT && stri >= P.num_tri) {   // cannot happen; never fault
+                            atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 1u);
+                            stri = HRT_NO_HIT;
+                        }
+                        if (stri != HRT_NO_HIT) {
+                            uint32_t smesh;
+                            theta = incidence_angle(tri_normal(stri, smesh), w);
+                        }
+                        // (issuing a record's stores one record late -- behind the next record's calls, whose
+                        // callees begin with s_waitcnt vmcnt(0) -- was measured: 10 more registers, +17 %)
+                        if (stri != HRT_NO_HIT && near1) {
+                            stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, 0.f);
+                            stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, 0.f);
+                            stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, 0.f);
+                            stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, 0.f);
+                            stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, 0.f);
+                        } else {
+                            unblocked = true;
+                            const float th_s = acos_f_ool(dot3(w, n));
+                            const float4 S = scatter_pattern(mat_s, mat_alpha, th_s, theta);
+                            float o0 = a0 * S.x - a1 * S.y;
+                            float o1 = a0 * S.y + a1 * S.x;
+                            float o2 = a2 * S.z - a3 * S.w;
+                            float o3 = a2 * S.w + a3 * S.z;
+                            float f2 = P.fsl_mult * d2rx;
+                            f2 *= f2;
+                            if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
+                            stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, o0);
+                            stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, o1);
+                            stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, o2);
+                            stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, o3);
+                            stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, tau + d2rx / kC);
+                            stf(rec_blk(P, pb, rx), R_DX * cap4, i4, -w.x);
+                            stf(rec_blk(P, pb, rx), R_DY * cap4, i4, -w.y);
+                            stf(rec_blk(P, pb, rx), R_DZ * cap4, i4, -w.z);
+                            stf(rec_blk(P, pb, rx), R_DFS * cap4, i4, dot3(sub3(w, d), mvel) * P.dop_mult);
+                        }
+                    }
+                    const unsigned long long m = __ballot(unblocked);
+                    if (lane == 0 && valid) mask_words(P, pb, rx)[i >> 6] = m;
+                }
             }
         }
 
@@ -1744,20 +1802,17 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             uint32_t ntri = 0;
             float nth = 0.f;
             if (valid) {
-                uint32_t ptri = ldu(res_blk(P, P.num_rx), 0u, i4);
                 if (ptri != HRT_NO_HIT && ptri >= P.num_tri) {       // cannot happen; never fault
                     atomicOr(const_cast<uint32_t *>(&counts[P.num_bounces + 1]), 2u);
                     ptri = HRT_NO_HIT;
                 }
                 if (ptri != HRT_NO_HIT) {
-                    const float pt = ldf(res_blk(P, P.num_rx), cap4, i4);
                     hit = true;
                     ntri = ptri;
-                    const F3 n = gather3(tri_r, HRT_TRI_FLOATS * 4u, ptri, 36u);
+                    uint32_t mesh;
+                    const F3 n = tri_normal(ptri, mesh);
                     nth = incidence_angle(n, d);
-                    const uint32_t mesh = ldu(tri_r, 0u, ptri * (HRT_TRI_FLOATS * 4u) + 76u);
-                    const uint32_t mat =
-                        ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
+                    const uint32_t mat = __float_as_uint(mesh_row(mesh).w);
                     float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
                     float fsl = P.fsl_mult * pt;
                     fsl *= fsl;
@@ -3059,9 +3114,14 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
     static const uint64_t max_grid = env_u64("HRT_SHADE_GRID", HRT_SHADE_GRID);
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
-    const size_t lds = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)P->num_rx * 16u + 32u;
-    hipLaunchKernelGGL(hrt_shade_kernel, dim3((uint32_t)blocks), dim3(HRT_BLOCK), lds,
-                       (hipStream_t)stream, *P, bounce);
+    const size_t lds0 = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)P->num_rx * 16u + 32u;
+    static const uint64_t nlds_off = env_u64("HRT_SHADE_NO_LDS_NORMALS", 0);
+    if (!nlds_off && P->num_tri <= kShadeLdsTri && P->num_mesh <= kShadeLdsMesh)
+        hipLaunchKernelGGL(hrt_shade_kernel<true>, dim3((uint32_t)blocks), dim3(HRT_BLOCK),
+                           lds0 + ((size_t)P->num_tri + P->num_mesh) * 16u, (hipStream_t)stream, *P, bounce);
+    else
+        hipLaunchKernelGGL(hrt_shade_kernel<false>, dim3((uint32_t)blocks), dim3(HRT_BLOCK), lds0,
+                           (hipStream_t)stream, *P, bounce);
     return (int)hipGetLastError();
 }
 
