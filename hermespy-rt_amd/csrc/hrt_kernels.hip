@@ -2108,13 +2108,6 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     const uint32_t chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
     const bool do_trace = FIRST || (b < P.num_bounces);
-    // All workgroups of the first generation start together, and a chunk cannot finish before the
-    // chunks in front of it have published: left alone the whole grid then runs in lock step -- every
-    // resident workgroup loads, traces, waits and stores at the same time, memory idle while the
-    // SIMDs work and vice versa.  The first generation therefore starts on a ramp (workgroup i
-    // i * stagger_clk cycles late); a slot that frees starts the next chunk, so the ramp carries on.
-    if (chunk < P.stagger_n && n_chunks > 2u * P.stagger_n)
-        for (uint32_t q = (chunk * P.stagger_clk) >> 10; q != 0u; --q) __builtin_amdgcn_s_sleep(16);   // 16 * 64 clocks
 
     const uint32_t T = P.num_tri;
     const uint32_t cap4 = (uint32_t)P.cap * 4u;
@@ -2130,7 +2123,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     int ph_i = 0;
 #define HRT_PHASE(col)                                                                           \
     do {                                                                                         \
-        if (tid == 0 && b == P.stagger_clk && chunk < 65536u) g_phase[chunk][ph_i++] = wall_clock64(); \
+        if (tid == 0 && b == P.phase_bounce && chunk < 65536u) g_phase[chunk][ph_i++] = wall_clock64(); \
     } while (0)
     HRT_PHASE(0);
 #else
@@ -2390,11 +2383,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
         const bool need_prefix = c_total != 0u || (chunk & 63u) == 63u || chunk + 1u == n_chunks;
         if (need_prefix) {   // (uniform over the workgroup)
             if (tid < 64u) {   // wave 0
-#ifdef HRT_EXP_NOWAIT   /* timing experiment only: WRONG offsets */
-                const uint32_t excl = chunk * MC / 2u;
-#else
                 const uint32_t excl = lb_exclusive(W, chunk, c_total, lane);
-#endif
                 if (lane == 0) {
                     L.wcnt[8] = excl;
                     if (chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length
@@ -3128,15 +3117,11 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
 int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
 {
     hrt_kparams Pc = *P_in;
-    static const uint64_t stag_n = env_u64("HRT_STAGGER_N", 0), stag_clk = env_u64("HRT_STAGGER_CLK", 0);
-    Pc.stagger_n = (uint32_t)stag_n;
-    Pc.stagger_clk = (uint32_t)stag_clk;
+#ifdef HRT_PHASE_STATS
+    Pc.phase_bounce = (uint32_t)env_u64("HRT_PHASE_BOUNCE", 0);
+#endif
     if (bounce != 0) Pc.los_blocks = 0;
     else if (Pc.los_blocks) Pc.los_blocks = (Pc.num_rx * Pc.num_tx + HRT_BLOCK / 64u - 1u) / (HRT_BLOCK / 64u);
-#ifdef HRT_PHASE_STATS
-    Pc.stagger_n = 0;
-    Pc.stagger_clk = (uint32_t)env_u64("HRT_PHASE_BOUNCE", 0);
-#endif
     const hrt_kparams *P = &Pc;
     if (P->cap / HRT_BLOCK + 1u > P->lb_chunks) return (int)hipErrorInvalidValue;   // (one word per chunk)
     static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);

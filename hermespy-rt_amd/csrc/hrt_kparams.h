@@ -139,7 +139,7 @@ typedef struct {
     uint64_t off_lb;
     uint32_t lb_stride, lb_chunks;
     uint32_t los_blocks;  /* fused launch 0: the last los_blocks workgroups of the grid do the LoS pass (0: own kernel) */
-    uint32_t stagger_n, stagger_clk;   /* fused kernels: the first stagger_n workgroups start stagger_clk * index cycles late */
+    uint32_t phase_bounce;   /* -DHRT_PHASE_STATS builds: the launch whose workgroups record their time stamps */
     uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
 } hrt_kparams;
 
