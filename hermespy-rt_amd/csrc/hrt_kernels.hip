@@ -1191,12 +1191,13 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, c
 
 // acos in double of the float dot product, stored to float, folded to [0, pi/2] with the
 // float pi (src/compute_paths.c:281-283).
-__device__ __noinline__ float incidence_angle(F3 n, F3 d)
+__device__ __forceinline__ float incidence_angle_inl(F3 n, F3 d)
 {
     float th = (float)acos((double)dot3(n, d));
     if (th > kPi * 0.5f) th = kPi - th;   // (double)th > (double)pi_f/2. is the same test
     return th;
 }
+__device__ __noinline__ float incidence_angle(F3 n, F3 d) { return incidence_angle_inl(n, d); }
 
 // float libm calls of the shading code: bit-exact restatements of the host libm (hrt_libm.h)
 __device__ __forceinline__ float sin_f(float x) { return hrt_sinf(x); }
@@ -1221,7 +1222,7 @@ __device__ __forceinline__ void complex_div(float ar, float ai, float br, float 
 // Shading is per hit, not per triangle test: it is kept OUT OF LINE so that its double-
 // precision polynomial constants and temporaries do not inflate the register allocation of
 // the intersection loops (174 -> ~80 VGPRs: 2 -> 5+ waves per SIMD).
-__device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th)
+__device__ __forceinline__ float4 fresnel_inl(float4 m0, float4 m1, float4 m2, float th)
 {
     float s1, c1;
     hrt_sincosf(th, &s1, &c1);   // sinf(th) and cosf(th) (:310, :325) from one reduction
@@ -1239,6 +1240,7 @@ __device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th
     R.x *= m2.w; R.y *= m2.w; R.z *= m2.w; R.w *= m2.w;
     return R;
 }
+__device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th) { return fresnel_inl(m0, m1, m2, th); }
 
 // src/compute_paths.c:359-415; s = scattering coefficient, alpha = s1_alpha (small integer)
 __device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s, float th_i)
@@ -2024,11 +2026,15 @@ __device__ __forceinline__ void bounce_fetch(TriPtr tri, Rsrc mesh_r, uint32_t p
     const uint32_t mesh = __float_as_uint(tri[HRT_ROW * ptri + 4].w);
     mat = ldu(mesh_r, 0u, mesh * (HRT_MESH_FLOATS * 4u) + 12u);
 }
+template <bool INL>
 __device__ __forceinline__ void bounce_apply(const float4 *l_mat, float fsl_mult, F3 n, uint32_t mat, float pt, F3 &o,
                                              F3 &d, float &a0, float &a1, float &a2, float &a3, float &tau, float &nth)
 {
-    nth = incidence_angle(n, d);
-    float4 R = fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
+    // (INL: the two shading functions inlined -- an out-of-line one begins with s_waitcnt vmcnt(0), i.e.
+    // waits for the previous packet's fifteen stores)
+    nth = INL ? incidence_angle_inl(n, d) : incidence_angle(n, d);
+    float4 R = INL ? fresnel_inl(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth)
+                   : fresnel(l_mat[4u * mat], l_mat[4u * mat + 1u], l_mat[4u * mat + 2u], nth);
     float fsl = fsl_mult * pt;
     fsl *= fsl;
     if (fsl > 1.f) { R.x /= fsl; R.y /= fsl; R.z /= fsl; R.w /= fsl; }
@@ -2066,6 +2072,9 @@ __device__ __forceinline__ void store_survivor(Rsrc out, uint32_t cap4, uint32_t
 }
 
 constexpr uint32_t kShortList = 256u * 1024u;   // entries: one packet per wave fills the chip once
+#ifndef HRT_FUSED_INLINE0
+#define HRT_FUSED_INLINE0 1
+#endif
 #ifndef HRT_FUSED_WAVES0
 #define HRT_FUSED_WAVES0 7   /* launch 0: at most 72 VGPRs (8 waves spill and are slower) */
 #endif
@@ -2416,7 +2425,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
                     fs0[k] = dot3(tv, d[k]) * P.dop_mult;
                     bounce_fetch(tri, mesh_r, h[k].tri, nk[k], matk[k]);
                 }
-                bounce_apply(L.mat, P.fsl_mult, nk[k], matk[k], h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k], tau[k], nth);
+                bounce_apply<(FIRST && HRT_FUSED_INLINE0)>(L.mat, P.fsl_mult, nk[k], matk[k], h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k], tau[k], nth);
                 const uint32_t k4 = (pos + before + lane_prefix(hm[k])) * 4u;
                 store_survivor(hit_out(P, b), cap4, k4, ray[k], h[k].tri, nth, fs0[k], o[k], d[k], a0[k], a1[k], a2[k],
                                a3[k], tau[k]);
