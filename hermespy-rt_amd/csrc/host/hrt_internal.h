@@ -46,6 +46,9 @@ typedef struct hrt_accel {
     float *pl_node[HRT_ACCEL_MAX_LEVELS];   /* [0] = cones of the 64-entry leaves */
     uint32_t *pl_index;          /* [pl_num_leaf * 64] table rows, HRT_NO_HIT padded */
     float *pl_rec;               /* [pl_num_leaf * 64][HRT_NODE_FLOATS]: p1.xyz, l, n.xyz, qs */
+    int planes;                  /* plane tree present (big, or the fine leaves) */
+    uint32_t num_fine;
+    float *fine;                 /* [num_fine][HRT_NODE_FLOATS]: sphere + Lambda of HRT_FINE_ROWS rows, or NULL */
 } hrt_accel;
 int hrt_accel_order(hrt_accel *a, const float *rows_ref_order, uint32_t T, int reorder);
 int hrt_accel_build(hrt_accel *a, const float *rows_table_order);

@@ -430,10 +430,12 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         i_node[k] = PART(A->node[k], (uint64_t)A->node_count[k] * HRT_NODE_FLOATS * 4);
     for (uint32_t k = 0; k < A->pl_levels; ++k)
         i_pl[k] = PART(A->pl_node[k], (uint64_t)A->pl_count[k] * HRT_NODE_FLOATS * 4);
-    if (A->big) {
+    int i_fine = -1;
+    if (A->planes) {
         i_pli = PART(A->pl_index, (uint64_t)A->pl_num_leaf * 64 * 4);
         i_plr = PART(A->pl_rec, (uint64_t)A->pl_num_leaf * 64 * HRT_NODE_FLOATS * 4);
     }
+    if (A->fine) i_fine = PART(A->fine, (uint64_t)A->num_fine * HRT_NODE_FLOATS * 4);
 #undef PART
     uint64_t total = 0;
     for (int k = 0; k < np; ++k) { offs[k] = total; total += round_up(len[k] ? len[k] : 1, 256); }
@@ -478,9 +480,13 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         ka->pl_count[k] = A->pl_count[k];
         ka->pl_node[k] = (const float *)(b + offs[i_pl[k]]);
     }
-    if (A->big) {
+    if (A->planes) {
         ka->pl_index = (const uint32_t *)(b + offs[i_pli]);
         ka->pl_rec = (const float *)(b + offs[i_plr]);
+    }
+    if (A->fine) {
+        ka->fine = (const float *)(b + offs[i_fine]);
+        ka->num_fine = A->num_fine;
     }
     {   /* bounding box of the finite vertices (cells of the re-sort keys), and whether to re-sort */
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};

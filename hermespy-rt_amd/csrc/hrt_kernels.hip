@@ -1154,6 +1154,204 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
     return {who, best};
 }
 
+// =====================================================================================
+// Acceleration structure, FINE LEAVES (variant 9; OPT-IN: HRT_ACCEL_FINE_MIN=n builds them for tables of
+// more than n triangles without the big-table trees -- slower than the 64-row leaves end to end, see
+// the end of this comment and DESIGN_ACCEL.md B.7).  Measured on a city of 25 000 triangles: after the re-sort 99 % of the packets
+// are usable, but 354 of the 391 leaves of 64 rows are NEAR a packet's lines (a leaf sphere there has
+// a radius of 60 m) and go through a full packet_culls round each -- 51 000 of the 70 000 instructions
+// of a trace.  Here the spheres are those of 16 consecutive rows (the order is a k-d order: any run of
+// rows is a compact cell), scanned FLAT, 64 spheres per round -- no tree, no dependent loads -- with
+// the big tables' criterion: a sphere is dropped when every line of the packet misses it by
+// m >= max(Lambda / 2, mu S); the triangles of dropped spheres that are nearly parallel to the rays
+// (|d.n| <= Gamma_i for some ray: the only ones the lemma's first term does not reject) are found
+// through the PLANE TREE and judged one by one, exactly as in closest_hit_big.  The rows of four near
+// spheres fill one packet_culls round.  Soundness: DESIGN_ACCEL.md B.2 / B.4 (the lemma does not care
+// how many triangles a sphere holds).  Measured (25 002-triangle city, 1 M rays): culling rounds per
+// trace 354 -> 28-43, candidates 379 -> 320 -- and 27.8 ms per step against 18.7: the plane-tree walk
+// (40-65 leaves of 64 records judged per trace: in a city every near-horizontal ray is "nearly
+// parallel" to all roofs and the ground) is 46 % of the trace time, and what is left is bound by the
+// dependent L2 round trips of the candidate walk, which the finer leaves do not shorten.
+// Per-wave LDS scratch `ws` (128 words): [0..15] queue tags, [16..23] node masks of the plane levels,
+// [24..27] their bases, [64..127] the four sphere indices of every queued fine round.
+// =====================================================================================
+template <typename TriPtr>
+__device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A, uint32_t num_tri, F3 o, F3 d,
+                                                bool valid, uint32_t lane, const Ball &B, const bool shadow, F3 apex,
+                                                unsigned long long *wmask, uint32_t *ws, [[maybe_unused]] int kind)
+{
+    const uint32_t *__restrict__ orig = A.orig;
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
+    const unsigned long long inval = HRT_BALLOT(!valid);
+    if (inval == ~0ull) return {who, best};
+    const Packet P = packet_bounds(B, d, valid, shadow, apex);
+    HRT_STAT(kind, 0, 1);
+    HRT_STAT(kind, 1, P.usable ? 1 : 0);
+    if (!P.usable) {   // too wide to cull: every triangle, exactly (as the other walks)
+        HRT_STAT(kind, 2, num_tri);
+        for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
+        return {who, best};
+    }
+    unsigned long long *nmask = reinterpret_cast<unsigned long long *>(ws + 16);
+    uint32_t *nbase = ws + 24, *wsub = ws + 64;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](unsigned long long v) {
+        return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | (unsigned long long)uni((uint32_t)v);
+    };
+    uint32_t qn = 0;
+#ifdef HRT_KERNEL_STATS
+    long long t_flush = 0, t_ph0 = clock64();
+#endif
+    auto flush = [&]() {
+#ifdef HRT_KERNEL_STATS
+        const long long tf0 = clock64();
+#endif
+        for (uint32_t e = 0; e < qn; ++e) {
+            const uint32_t tag = uni(ws[e]);
+            unsigned long long m = uni64(wmask[e]);
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t j = (tag & 0x80000000u) ? A.pl_index[(tag & 0x7fffffffu) * 64u + b]
+                                                       : uni(wsub[4u * e + (b >> 4)]) * HRT_FINE_ROWS + (b & 15u);
+                HRT_STAGED_BODY(j)
+            }
+        }
+        qn = 0;
+#ifdef HRT_KERNEL_STATS
+        t_flush += clock64() - tf0;
+#endif
+    };
+    // ---- fine leaves, flat: lane l looks at sphere base + l ----
+    {
+        const float4 *fine = reinterpret_cast<const float4 *>(A.fine);
+        const uint32_t nfine = A.num_fine;
+        for (uint32_t base = 0; base < nfine; base += 64u) {
+            const uint32_t idx = base + lane;
+            const bool has = idx < nfine;
+            const uint32_t ic = has ? idx : base;
+            const float4 n0 = fine[2u * ic], n1 = fine[2u * ic + 1u];
+            const LeafFar f = leaf_far(P, n0, n1);
+            const bool far = f.m > fmaxf(0.5f * n1.x, kMu * f.S);   // NaN / inf: not far
+            unsigned long long near = HRT_BALLOT(has && !far);
+            HRT_STAT(kind, 8, 1);
+            while (near) {   // the rows of four near spheres make one culling round
+                uint32_t s4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s4[q] = HRT_NO_HIT;
+                    if (near) {
+                        s4[q] = base + (uint32_t)__builtin_ctzll(near);
+                        near &= near - 1ull;
+                    }
+                }
+                const uint32_t g = lane >> 4;
+                const uint32_t mine = g == 0u ? s4[0] : (g == 1u ? s4[1] : (g == 2u ? s4[2] : s4[3]));
+                const uint32_t jl = mine * HRT_FINE_ROWS + (lane & 15u);
+                bool cand = mine != HRT_NO_HIT && jl < num_tri;
+                if (cand)
+                    cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1], tri[HRT_ROW * jl + 2],
+                                         tri[HRT_ROW * jl + 3], tri[HRT_ROW * jl + 4]);
+                const unsigned long long cm = HRT_BALLOT(cand);
+                HRT_STAT(kind, 2, __popcll(cm));
+                HRT_STAT(kind, 7, 1);
+                if (cm != 0ull) {
+                    if (lane == 0) {
+                        ws[qn] = 0u;
+                        wmask[qn] = cm;
+                        wsub[4u * qn] = s4[0]; wsub[4u * qn + 1u] = s4[1]; wsub[4u * qn + 2u] = s4[2]; wsub[4u * qn + 3u] = s4[3];
+                    }
+                    if (++qn == kMaskRounds) flush();
+                }
+            }
+        }
+    }
+#ifdef HRT_KERNEL_STATS
+    const long long t_ph1 = clock64(), t_fl1 = t_flush;
+#endif
+    // ---- plane tree: level pl_levels-1 = top ... level 0 = cones of the 64-entry leaves (as closest_hit_big) ----
+    if (!(A.dbg & 2u)) {   // (HRT_ACCEL_DEBUG bit 1 skips it: UNSOUND, timing experiments only)
+        const uint32_t L = A.pl_levels - 1u;
+        auto visit = [&](uint32_t k, uint32_t base) -> unsigned long long {
+            const uint32_t count = k == 0u ? A.pl_count[0] : (k == 1u ? A.pl_count[1] : A.pl_count[2]);
+            const float4 *arr = reinterpret_cast<const float4 *>(k == 0u ? A.pl_node[0] : (k == 1u ? A.pl_node[1] : A.pl_node[2]));
+            const uint32_t idx = base + lane;
+            const bool has = idx < count;
+            const uint32_t ic = has ? idx : base;
+            const float4 n0 = arr[2u * ic], n1 = arr[2u * ic + 1u];
+            const float sdot = fabsf(fdot3(P.ax, {n0.x, n0.y, n0.z}));
+            const float thr = __builtin_fmaf(P.sina, n1.x, P.cosa * n0.w) * 1.0001f + 1e-6f;
+            const bool skip = sdot > thr;                    // NaN: visit
+            HRT_STAT(kind, 9, 1);
+            return HRT_BALLOT(has && !skip);
+        };
+        uint32_t k = L;
+        {
+            const unsigned long long m0 = visit(k, 0u);
+            if (lane == 0) { nmask[k] = m0; nbase[k] = 0u; }
+        }
+        for (;;) {
+            const unsigned long long m = uni64(nmask[k]);
+            if (m == 0ull) {
+                if (k == L) break;
+                ++k;
+                continue;
+            }
+            const uint32_t b = (uint32_t)__builtin_ctzll(m);
+            const uint32_t idx = uni(nbase[k]) + b;
+            if (lane == 0) nmask[k] = m & (m - 1ull);
+            if (k == 0u) {   // a leaf of 64 triangle ids: each judged on its own
+                const uint32_t e = idx * 64u + lane;
+                const uint32_t j = A.pl_index[e];
+                const float4 *rec = reinterpret_cast<const float4 *>(A.pl_rec) + 2u * e;
+                const float4 r0 = rec[0], r1 = rec[1];
+                bool cand = j != HRT_NO_HIT;
+                HRT_STAT(kind, 10, 1);
+                if (cand) {
+                    const F3 n = {r1.x, r1.y, r1.z};
+                    const float amin = __builtin_fmaf(fabsf(fdot3(P.ax, n)), P.cosa, -P.sina);
+                    bool safe = amin > kGammaPerQs * r1.w;           // the spheres vouch for it
+                    if (!safe) {
+                        const LeafFar f = leaf_far(P, r0, make_float4(r0.w, 0.f, 0.f, 0.f));   // ball (p1, l)
+                        const F3 sb = sub3(P.bc, {r0.x, r0.y, r0.z});
+                        const float hmin = fabsf(fdot3(n, sb)) - P.br * 1.0001f -
+                                           2e-6f * ((fabsf(sb.x) + fabsf(sb.y)) + fabsf(sb.z));
+                        const float Ti = r1.w * (f.S + r0.w);
+                        safe = (f.m > 0.f) & ((amin * f.phi > Ti) | (hmin * f.kappa > Ti));
+                    }
+                    cand = !safe;
+                }
+                if (HRT_BALLOT(cand) != 0ull) {
+                    HRT_STAT(kind, 11, 1);
+                    if (cand)
+                        cand = !packet_culls(P, tri[HRT_ROW * j], tri[HRT_ROW * j + 1], tri[HRT_ROW * j + 2],
+                                             tri[HRT_ROW * j + 3], tri[HRT_ROW * j + 4]);
+                    const unsigned long long cm = HRT_BALLOT(cand);
+                    if (cm != 0ull) {
+                        if (lane == 0) { ws[qn] = idx | 0x80000000u; wmask[qn] = cm; }
+                        if (++qn == kMaskRounds) flush();
+                    }
+                }
+            } else {
+                --k;
+                const unsigned long long mk = visit(k, idx * 64u);
+                if (lane == 0) { nmask[k] = mk; nbase[k] = idx * 64u; }
+            }
+        }
+    }
+    flush();
+#ifdef HRT_KERNEL_STATS
+    {   // cols 13 / 14 / 15: clocks of the fine scan + culling, of the plane tree, of the staged tests
+        const long long t_end = clock64();
+        HRT_STAT(kind, 13, (t_ph1 - t_ph0) - t_fl1);
+        HRT_STAT(kind, 14, (t_end - t_ph1) - (t_flush - t_fl1));
+        HRT_STAT(kind, 15, t_flush);
+    }
+#endif
+    return {who, best};
+}
+
 #ifndef HRT_TRACE_VARIANT_DEFAULT
 #define HRT_TRACE_VARIANT_DEFAULT 7   /* auto */
 #endif
@@ -1183,6 +1381,9 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, c
     } else if constexpr (VARIANT == 6) {
         return closest_hit_big(tri, leaf, A, num_tri, o, d, valid, lane, shadow, apex, wmask,
                                reinterpret_cast<uint32_t *>(wleaf), kind);
+    } else if constexpr (VARIANT == 9) {
+        return closest_hit_fine(tri, A, num_tri, o, d, valid, lane, B, shadow, apex, wmask,
+                                reinterpret_cast<uint32_t *>(wleaf), kind);
     } else {
         return closest_hit_tree<(VARIANT == 5)>(tri, tg, leaf, orig, num_tri, o, d, valid, lane, B, shadow,
                                                 apex, wmask, wleaf, kind);
@@ -1440,11 +1641,12 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
     float4 *l_rx = TRI_IN_LDS ? l_leaf + 2u * n_leaf : lds;
     unsigned long long *l_mask = reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
                                  (tid >> 6) * kMaskRounds;
+    // (per wave 2 * kMaskRounds float4 = 128 words of scratch: leaf constants / the tree walks' stacks and queues)
     float4 *l_wleaf = reinterpret_cast<float4 *>(reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
-                                                 (HRT_BLOCK / 64u) * kMaskRounds) + (tid >> 6) * kMaskRounds;
+                                                 (HRT_BLOCK / 64u) * kMaskRounds) + (tid >> 6) * 2u * kMaskRounds;
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(
         reinterpret_cast<float4 *>(reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
-                                   (HRT_BLOCK / 64u) * kMaskRounds) + (HRT_BLOCK / 64u) * kMaskRounds);
+                                   (HRT_BLOCK / 64u) * kMaskRounds) + (HRT_BLOCK / 64u) * 2u * kMaskRounds);
     if (TRI_IN_LDS) {
         for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
         if constexpr (VARIANT >= 4) {   // guard pairs and leaf records: only the tree variants read them
@@ -1546,7 +1748,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
                              : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane,
                                                     ball, shadow, apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
 #ifdef HRT_KERNEL_STATS
-        if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks
+        if (lane == 0 && VARIANT != 9) {   // per wave-trace: longest and total duration in shader clocks
             const unsigned long long dt = (unsigned long long)(clock64() - t_unit0);
             atomicMax(&g_stats[shadow ? 2 : (first ? 0 : 1)][13], dt);
             atomicAdd(&g_stats[shadow ? 2 : (first ? 0 : 1)][14], dt);
@@ -1985,7 +2187,7 @@ __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chun
 
 // LDS image shared by the fused kernels (hrt_hip_launch_fused sizes it):
 // [T x 5 float4 rows | T float2 guard pairs, padded to 16 B | 2 float4 per leaf] (only if staged)
-// [num_rx float4 RX pos][4 waves x 16 u64 masks][4 waves x 16 float4 leaf constants][64 u32]
+// [num_rx float4 RX pos][4 waves x 16 u64 masks][4 waves x 32 float4 per-wave scratch][64 u32]
 // [17 x 4 float4 materials][64 float4 TX pos]
 constexpr uint32_t kLdsTx = 64u;
 struct FusedLds {
@@ -2005,8 +2207,8 @@ __device__ __forceinline__ FusedLds fused_lds(float4 *lds, uint32_t T, uint32_t 
     unsigned long long *m0 = reinterpret_cast<unsigned long long *>(L.rx + num_rx);
     L.mask = m0 + wave * kMaskRounds;
     float4 *w0 = reinterpret_cast<float4 *>(m0 + (HRT_BLOCK / 64u) * kMaskRounds);
-    L.wleaf = w0 + wave * kMaskRounds;
-    L.wcnt = reinterpret_cast<uint32_t *>(w0 + (HRT_BLOCK / 64u) * kMaskRounds);
+    L.wleaf = w0 + wave * 2u * kMaskRounds;   // (128 words of scratch per wave)
+    L.wcnt = reinterpret_cast<uint32_t *>(w0 + (HRT_BLOCK / 64u) * 2u * kMaskRounds);
     L.mat = reinterpret_cast<float4 *>(L.wcnt + 64);
     L.tx = L.mat + 4u * HRT_NUM_MATERIALS;   // the first kLdsTx TX positions (launch 0)
     return L;
@@ -3074,7 +3276,7 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;   // packet culling: single-block build
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 16u) + 16u;
+                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 32u) + 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
@@ -3082,9 +3284,12 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     // block of 1024 triangles (where the live list is re-sorted between bounces, so that most leaves
     // ARE far from a packet: city of 25 002 triangles 22.2 -> 17.9 ms, of 100 002 100 -> 87); the flat
     // walk on small tables (C3: 1.67 vs 1.81 ms)
-    const bool trees = P->acc.big && (variant >= 4);
+    const bool trees = P->acc.big && (variant >= 4) && variant != 9;
     const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
-    if (in_lds) {
+    // fine leaves + plane tree where the host built them (opt-in, HRT_ACCEL_FINE_MIN): auto, or variant 9
+    const bool fine = !in_lds && !trees && P->acc.fine != nullptr && (variant == 7 || variant == 9);
+    if (fine) launch_trace_t<false, 9>(P, bounce, nb, lds, st, &err);
+    else if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
         else if (flat) {
@@ -3141,17 +3346,19 @@ int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 16u) + 64u * 4u +
+                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 32u) + 64u * 4u +
                        (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + kLdsTx * 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     // the same choice of intersection loop as hrt_hip_launch_trace; on tables of a handful of
     // triangles (auto) the staged walk over all of them is cheaper than a culling round
     static const uint64_t staged_max = env_u64("HRT_FUSE_STAGED_MAX_TRI", 6);
-    const bool trees = P->acc.big && (variant >= 4);
+    const bool trees = P->acc.big && (variant >= 4) && variant != 9;
     const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
     const bool staged = variant == 1 || (variant == 7 && T <= staged_max);
-    if (in_lds) {
+    const bool fine = !in_lds && !trees && P->acc.fine != nullptr && (variant == 7 || variant == 9);
+    if (fine) launch_fused_t<false, 9>(P, bounce, lds, st, &err);
+    else if (in_lds) {
         if (variant == 0) launch_fused_t<true, 0>(P, bounce, lds, st, &err);
         else if (staged) launch_fused_t<true, 1>(P, bounce, lds, st, &err);
         else if (flat) {

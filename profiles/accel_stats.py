@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 lib.load().hrt_debug_kernel_stats(0, arr, 0)
 cols = ["wave_traces", "usable_full", "candidates", "stage2", "stage3", "exact", "subpackets", "cull_rounds",
         "sphere_rounds", "plane_rounds", "plane_leaves", "plane_leaves_flagged", "flagged", "max_clk", "sum_clk"]
-cols = cols[:13] + ["max_clk", "sum_clk"]
+cols = cols[:13] + ["max_clk", "sum_clk", "clk15"]
 for k, name in enumerate(("primary0", "primary", "shadow")):
     row = {c: int(arr[k * 16 + j]) for j, c in enumerate(cols)}
     wt = max(1, row["wave_traces"])
