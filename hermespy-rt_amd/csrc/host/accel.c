@@ -248,11 +248,12 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
         L[4] = up(lam);
     }
     /* fine leaves: spheres of HRT_FINE_ROWS consecutive rows (the order is a k-d order: any run of rows is
-     * a compact cell), for the flat scan of closest_hit_fine -- an OPT-IN walk (HRT_ACCEL_FINE_MIN=n: tables
-     * of more than n triangles): parity-green, 10x fewer culling rounds than the 64-row leaves, but slower
-     * end to end on the generated cities (the plane-tree walk it needs as its guard; DESIGN_ACCEL.md B.7). */
-    int want_fine = 0;
+     * a compact cell), for the flat scan of closest_hit_fine -- the default walk of tables of more than
+     * HRT_FINE_MIN_TRI triangles that are not "big" (HRT_ACCEL_FINE_MIN=n replaces the threshold;
+     * HRT_ACCEL_FINE=0 brings the 64-row leaf walk back). */
+    int want_fine = T > HRT_FINE_MIN_TRI;
     { const char *mv = getenv("HRT_ACCEL_FINE_MIN"); if (mv && *mv) want_fine = (unsigned long long)T > strtoull(mv, NULL, 10); }
+    { const char *fv = getenv("HRT_ACCEL_FINE"); if (fv && *fv && atoi(fv) == 0) want_fine = 0; }
     if (want_fine) {
         const uint32_t nfn = (T + HRT_FINE_ROWS - 1u) / HRT_FINE_ROWS;
         a->fine = (float *)calloc((size_t)nfn * HRT_NODE_FLOATS, sizeof(float));

@@ -583,6 +583,10 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 #define HRT_STAGED_BODY(J)                                                                      \
     {                                                                                           \
         const float4 q0 = tri[HRT_ROW * (J)], q1 = tri[HRT_ROW * (J) + 1], q2 = tri[HRT_ROW * (J) + 2];           \
+        HRT_STAGED_TEST(J, q0, q1, q2)                                                          \
+    }
+#define HRT_STAGED_TEST(J, q0, q1, q2)                                                          \
+    {                                                                                           \
         const F3 v1 = {q0.x, q0.y, q0.z};                                                       \
         const F3 e1 = {q0.w, q1.x, q1.y};                                                       \
         const F3 e2 = {q1.z, q1.w, q2.x};                                                       \
@@ -633,6 +637,15 @@ __device__ __forceinline__ bool packet_culls(const Packet &P, float4 q0, float4 
 // packet description and the culling temporaries are dead while the intersection tests run
 // (and vice versa), which is what keeps the kernel's register allocation low.
 constexpr uint32_t kMaskRounds = 16;
+// Per-wave LDS scratch of the trace / fused kernels, in float4: 2 * kMaskRounds words-of-four for the
+// walks (leaf constants, stacks, queues) and -- for the fine-leaves walk (variant 9), whose table is
+// read from GLOBAL memory -- a buffer of kCandBuf candidate rows (3 float4 of the row + its index):
+// the lane that finds a candidate in a culling round has the row in its registers and parks it
+// here, so that the candidate walk reads LDS instead of paying a dependent L2 round trip per
+// candidate.  (The 64-row leaf walk gains nothing from it: it is bound by the instructions of its
+// ~350 culling rounds per trace, not by its candidates.)
+constexpr uint32_t kCandBuf = 64u;
+__host__ __device__ constexpr uint32_t wave_scratch4(bool cand_buf) { return 2u * kMaskRounds + (cand_buf ? 4u * kCandBuf : 0u); }
 
 // cube-map cell of a direction (shared with the host builder, problem.c: rxt_cell_dir): face =
 // major axis + 3 * (major < 0), (u, v) = the two other components over the (signed) major one
@@ -1155,25 +1168,24 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
 }
 
 // =====================================================================================
-// Acceleration structure, FINE LEAVES (variant 9; OPT-IN: HRT_ACCEL_FINE_MIN=n builds them for tables of
-// more than n triangles without the big-table trees -- slower than the 64-row leaves end to end, see
-// the end of this comment and DESIGN_ACCEL.md B.7).  Measured on a city of 25 000 triangles: after the re-sort 99 % of the packets
-// are usable, but 354 of the 391 leaves of 64 rows are NEAR a packet's lines (a leaf sphere there has
-// a radius of 60 m) and go through a full packet_culls round each -- 51 000 of the 70 000 instructions
-// of a trace.  Here the spheres are those of 16 consecutive rows (the order is a k-d order: any run of
-// rows is a compact cell), scanned FLAT, 64 spheres per round -- no tree, no dependent loads -- with
-// the big tables' criterion: a sphere is dropped when every line of the packet misses it by
-// m >= max(Lambda / 2, mu S); the triangles of dropped spheres that are nearly parallel to the rays
-// (|d.n| <= Gamma_i for some ray: the only ones the lemma's first term does not reject) are found
-// through the PLANE TREE and judged one by one, exactly as in closest_hit_big.  The rows of four near
-// spheres fill one packet_culls round.  Soundness: DESIGN_ACCEL.md B.2 / B.4 (the lemma does not care
-// how many triangles a sphere holds).  Measured (25 002-triangle city, 1 M rays): culling rounds per
-// trace 354 -> 28-43, candidates 379 -> 320 -- and 27.8 ms per step against 18.7: the plane-tree walk
-// (40-65 leaves of 64 records judged per trace: in a city every near-horizontal ray is "nearly
-// parallel" to all roofs and the ground) is 46 % of the trace time, and what is left is bound by the
-// dependent L2 round trips of the candidate walk, which the finer leaves do not shorten.
-// Per-wave LDS scratch `ws` (128 words): [0..15] queue tags, [16..23] node masks of the plane levels,
-// [24..27] their bases, [64..127] the four sphere indices of every queued fine round.
+// Acceleration structure, FINE LEAVES (variant 9: the default walk of tables of more than
+// HRT_FINE_MIN_TRI triangles without the big-table trees).  Measured on a city of 25 000 triangles:
+// after the re-sort 99 % of the packets are usable, but 354 of the 391 leaves of 64 rows are NEAR a
+// packet's lines (a leaf sphere there has a radius of 60 m) and go through a full packet_culls round
+// each -- 51 000 of the 70 000 instructions of a trace.  Here the spheres are those of 16 consecutive
+// rows (the order is a k-d order: any run of rows is a compact cell), scanned FLAT, 64 spheres per
+// round -- no tree, no dependent loads -- with the big tables' criterion: a sphere is dropped when every
+// line of the packet misses it by m >= max(Lambda / 2, mu S); the triangles of dropped spheres that
+// are nearly parallel to the rays (|d.n| <= Gamma_i for some ray: the only ones the lemma's first term
+// does not reject) are found through the PLANE TREE and judged one by one, exactly as in
+// closest_hit_big.  The rows of four near spheres fill one packet_culls round (28-43 rounds per trace
+// instead of 354), and a candidate's row is parked in LDS by the lane that culled it (wave_scratch4):
+// with the candidates read back from the table the walk was bound by one L2 round trip per candidate
+// and SLOWER than the 64-row leaves (27.8 against 18.7 ms per step); with the buffer 15.6 (100 002
+// triangles: 88.6 -> 67.5).  Soundness: DESIGN_ACCEL.md B.2 / B.4 (the lemma does not care how many
+// triangles a sphere holds).
+// Per-wave LDS scratch `ws`: words [16..23] node masks of the plane levels, [24..27] their bases; behind
+// the 128 words the buffer of kCandBuf candidate rows (wave_scratch4).
 // =====================================================================================
 template <typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A, uint32_t num_tri, F3 o, F3 d,
@@ -1194,34 +1206,35 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
         return {who, best};
     }
     unsigned long long *nmask = reinterpret_cast<unsigned long long *>(ws + 16);
-    uint32_t *nbase = ws + 24, *wsub = ws + 64;
+    uint32_t *nbase = ws + 24;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto uni64 = [&](unsigned long long v) {
         return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | (unsigned long long)uni((uint32_t)v);
     };
-    uint32_t qn = 0;
-#ifdef HRT_KERNEL_STATS
-    long long t_flush = 0, t_ph0 = clock64();
-#endif
+    // candidates: their rows are parked in the wave's LDS buffer by the lane that just culled them (it has
+    // the row in registers) and walked from there -- no load from the table in the candidate walk
+    float4 *cbuf = reinterpret_cast<float4 *>(ws) + 2u * kMaskRounds;
+    uint32_t nbuf = 0u;
     auto flush = [&]() {
-#ifdef HRT_KERNEL_STATS
-        const long long tf0 = clock64();
-#endif
-        for (uint32_t e = 0; e < qn; ++e) {
-            const uint32_t tag = uni(ws[e]);
-            unsigned long long m = uni64(wmask[e]);
-            while (m) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1ull;
-                const uint32_t j = (tag & 0x80000000u) ? A.pl_index[(tag & 0x7fffffffu) * 64u + b]
-                                                       : uni(wsub[4u * e + (b >> 4)]) * HRT_FINE_ROWS + (b & 15u);
-                HRT_STAGED_BODY(j)
-            }
+        for (uint32_t e = 0; e < nbuf; ++e) {
+            const float4 *slot = cbuf + 4u * e;
+            const float4 c0 = slot[0], c1 = slot[1], c2 = slot[2];
+            const uint32_t j = uni(__float_as_uint(slot[3].x));
+            HRT_STAGED_TEST(j, c0, c1, c2)
         }
-        qn = 0;
-#ifdef HRT_KERNEL_STATS
-        t_flush += clock64() - tf0;
-#endif
+        nbuf = 0u;
+    };
+    auto park = [&](bool cand, uint32_t j, float4 c0, float4 c1, float4 c2) {   // all lanes call (uniform)
+        const unsigned long long cm = HRT_BALLOT(cand);
+        const uint32_t n = (uint32_t)__popcll(cm);
+        if (n == 0u) return;
+        if (nbuf + n > kCandBuf) flush();
+        if (cand) {
+            float4 *slot = cbuf + 4u * (nbuf + lane_prefix(cm));
+            slot[0] = c0; slot[1] = c1; slot[2] = c2;
+            slot[3] = make_float4(__uint_as_float(j), 0.f, 0.f, 0.f);
+        }
+        nbuf += n;
     };
     // ---- fine leaves, flat: lane l looks at sphere base + l ----
     {
@@ -1250,26 +1263,17 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
                 const uint32_t mine = g == 0u ? s4[0] : (g == 1u ? s4[1] : (g == 2u ? s4[2] : s4[3]));
                 const uint32_t jl = mine * HRT_FINE_ROWS + (lane & 15u);
                 bool cand = mine != HRT_NO_HIT && jl < num_tri;
-                if (cand)
-                    cand = !packet_culls(P, tri[HRT_ROW * jl], tri[HRT_ROW * jl + 1], tri[HRT_ROW * jl + 2],
-                                         tri[HRT_ROW * jl + 3], tri[HRT_ROW * jl + 4]);
-                const unsigned long long cm = HRT_BALLOT(cand);
-                HRT_STAT(kind, 2, __popcll(cm));
-                HRT_STAT(kind, 7, 1);
-                if (cm != 0ull) {
-                    if (lane == 0) {
-                        ws[qn] = 0u;
-                        wmask[qn] = cm;
-                        wsub[4u * qn] = s4[0]; wsub[4u * qn + 1u] = s4[1]; wsub[4u * qn + 2u] = s4[2]; wsub[4u * qn + 3u] = s4[3];
-                    }
-                    if (++qn == kMaskRounds) flush();
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
+                if (cand) {
+                    c0 = tri[HRT_ROW * jl]; c1 = tri[HRT_ROW * jl + 1]; c2 = tri[HRT_ROW * jl + 2];
+                    cand = !packet_culls(P, c0, c1, c2, tri[HRT_ROW * jl + 3], tri[HRT_ROW * jl + 4]);
                 }
+                HRT_STAT(kind, 2, __popcll(HRT_BALLOT(cand)));
+                HRT_STAT(kind, 7, 1);
+                park(cand, jl, c0, c1, c2);
             }
         }
     }
-#ifdef HRT_KERNEL_STATS
-    const long long t_ph1 = clock64(), t_fl1 = t_flush;
-#endif
     // ---- plane tree: level pl_levels-1 = top ... level 0 = cones of the 64-entry leaves (as closest_hit_big) ----
     if (!(A.dbg & 2u)) {   // (HRT_ACCEL_DEBUG bit 1 skips it: UNSOUND, timing experiments only)
         const uint32_t L = A.pl_levels - 1u;
@@ -1324,14 +1328,12 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
                 }
                 if (HRT_BALLOT(cand) != 0ull) {
                     HRT_STAT(kind, 11, 1);
-                    if (cand)
-                        cand = !packet_culls(P, tri[HRT_ROW * j], tri[HRT_ROW * j + 1], tri[HRT_ROW * j + 2],
-                                             tri[HRT_ROW * j + 3], tri[HRT_ROW * j + 4]);
-                    const unsigned long long cm = HRT_BALLOT(cand);
-                    if (cm != 0ull) {
-                        if (lane == 0) { ws[qn] = idx | 0x80000000u; wmask[qn] = cm; }
-                        if (++qn == kMaskRounds) flush();
+                    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
+                    if (cand) {
+                        c0 = tri[HRT_ROW * j]; c1 = tri[HRT_ROW * j + 1]; c2 = tri[HRT_ROW * j + 2];
+                        cand = !packet_culls(P, c0, c1, c2, tri[HRT_ROW * j + 3], tri[HRT_ROW * j + 4]);
                     }
+                    park(cand, j, c0, c1, c2);
                 }
             } else {
                 --k;
@@ -1341,14 +1343,6 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
         }
     }
     flush();
-#ifdef HRT_KERNEL_STATS
-    {   // cols 13 / 14 / 15: clocks of the fine scan + culling, of the plane tree, of the staged tests
-        const long long t_end = clock64();
-        HRT_STAT(kind, 13, (t_ph1 - t_ph0) - t_fl1);
-        HRT_STAT(kind, 14, (t_end - t_ph1) - (t_flush - t_fl1));
-        HRT_STAT(kind, 15, t_flush);
-    }
-#endif
     return {who, best};
 }
 
@@ -1643,10 +1637,10 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
                                  (tid >> 6) * kMaskRounds;
     // (per wave 2 * kMaskRounds float4 = 128 words of scratch: leaf constants / the tree walks' stacks and queues)
     float4 *l_wleaf = reinterpret_cast<float4 *>(reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
-                                                 (HRT_BLOCK / 64u) * kMaskRounds) + (tid >> 6) * 2u * kMaskRounds;
+                                                 (HRT_BLOCK / 64u) * kMaskRounds) + (tid >> 6) * wave_scratch4(VARIANT == 9);
     uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(
         reinterpret_cast<float4 *>(reinterpret_cast<unsigned long long *>(l_rx + P.num_rx) +
-                                   (HRT_BLOCK / 64u) * kMaskRounds) + (HRT_BLOCK / 64u) * 2u * kMaskRounds);
+                                   (HRT_BLOCK / 64u) * kMaskRounds) + (HRT_BLOCK / 64u) * wave_scratch4(VARIANT == 9));
     if (TRI_IN_LDS) {
         for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
         if constexpr (VARIANT >= 4) {   // guard pairs and leaf records: only the tree variants read them
@@ -1748,7 +1742,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
                              : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane,
                                                     ball, shadow, apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
 #ifdef HRT_KERNEL_STATS
-        if (lane == 0 && VARIANT != 9) {   // per wave-trace: longest and total duration in shader clocks
+        if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks
             const unsigned long long dt = (unsigned long long)(clock64() - t_unit0);
             atomicMax(&g_stats[shadow ? 2 : (first ? 0 : 1)][13], dt);
             atomicAdd(&g_stats[shadow ? 2 : (first ? 0 : 1)][14], dt);
@@ -2196,7 +2190,7 @@ struct FusedLds {
     unsigned long long *mask;
     uint32_t *wcnt;
 };
-template <bool TRI_IN_LDS>
+template <bool TRI_IN_LDS, bool CAND_BUF>
 __device__ __forceinline__ FusedLds fused_lds(float4 *lds, uint32_t T, uint32_t n_leaf, uint32_t num_rx, uint32_t wave)
 {
     FusedLds L;
@@ -2207,8 +2201,8 @@ __device__ __forceinline__ FusedLds fused_lds(float4 *lds, uint32_t T, uint32_t 
     unsigned long long *m0 = reinterpret_cast<unsigned long long *>(L.rx + num_rx);
     L.mask = m0 + wave * kMaskRounds;
     float4 *w0 = reinterpret_cast<float4 *>(m0 + (HRT_BLOCK / 64u) * kMaskRounds);
-    L.wleaf = w0 + wave * 2u * kMaskRounds;   // (128 words of scratch per wave)
-    L.wcnt = reinterpret_cast<uint32_t *>(w0 + (HRT_BLOCK / 64u) * 2u * kMaskRounds);
+    L.wleaf = w0 + wave * wave_scratch4(CAND_BUF);   // (per-wave scratch, + the candidate buffer of the fine walk)
+    L.wcnt = reinterpret_cast<uint32_t *>(w0 + (HRT_BLOCK / 64u) * wave_scratch4(CAND_BUF));
     L.mat = reinterpret_cast<float4 *>(L.wcnt + 64);
     L.tx = L.mat + 4u * HRT_NUM_MATERIALS;   // the first kLdsTx TX positions (launch 0)
     return L;
@@ -2326,7 +2320,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     const float2 *g_tg = reinterpret_cast<const float2 *>(P.acc.tg);
     const float4 *g_leaf = reinterpret_cast<const float4 *>(P.acc.leaf);
     const uint32_t n_leaf = P.acc.num_leaf;
-    const FusedLds L = fused_lds<TRI_IN_LDS>(lds, T, n_leaf, P.num_rx, wave);
+    const FusedLds L = fused_lds<TRI_IN_LDS, (VARIANT == 9)>(lds, T, n_leaf, P.num_rx, wave);
 #ifdef HRT_PHASE_STATS
     // (make EXTRA=-DHRT_PHASE_STATS) time stamps of a workgroup's life (thread 0, 100 MHz wall clock):
     // g_phase[chunk] = {start, loads + staging done, traces + publish done, records done, prefix
@@ -3275,8 +3269,10 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
     const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;   // packet culling: single-block build
+    const bool fine_pre = !in_lds && !(P->acc.big && variant >= 4 && variant != 9) && P->acc.fine != nullptr &&
+                          (variant == 7 || variant == 9);
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 32u) + 16u;
+                       (HRT_BLOCK / 64u) * (kMaskRounds * 8u + wave_scratch4(fine_pre) * 16u) + 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     const uint32_t nb = (uint32_t)blocks;
@@ -3286,7 +3282,7 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     // walk on small tables (C3: 1.67 vs 1.81 ms)
     const bool trees = P->acc.big && (variant >= 4) && variant != 9;
     const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
-    // fine leaves + plane tree where the host built them (opt-in, HRT_ACCEL_FINE_MIN): auto, or variant 9
+    // fine leaves + plane tree where the host built them (beyond HRT_FINE_MIN_TRI triangles): auto, or variant 9
     const bool fine = !in_lds && !trees && P->acc.fine != nullptr && (variant == 7 || variant == 9);
     if (fine) launch_trace_t<false, 9>(P, bounce, nb, lds, st, &err);
     else if (in_lds) {
@@ -3345,8 +3341,10 @@ int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
     const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;
+    const bool fine_pre = !in_lds && !(P->acc.big && variant >= 4 && variant != 9) && P->acc.fine != nullptr &&
+                          (variant == 7 || variant == 9);
     const size_t lds = (in_lds ? (size_t)tri_bytes : 0u) + (size_t)P->num_rx * 16u +
-                       (HRT_BLOCK / 64u) * kMaskRounds * (8u + 32u) + 64u * 4u +
+                       (HRT_BLOCK / 64u) * (kMaskRounds * 8u + wave_scratch4(fine_pre) * 16u) + 64u * 4u +
                        (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + kLdsTx * 16u;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;

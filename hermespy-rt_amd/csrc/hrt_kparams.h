@@ -57,13 +57,14 @@ typedef struct {
     const float *pl_node[HRT_ACCEL_MAX_LEVELS];
     const uint32_t *pl_index;
     const float *pl_rec;
-    /* fine leaves (opt-in, HRT_ACCEL_FINE_MIN): one sphere record (c.xyz, R, Lambda) per HRT_FINE_ROWS
-     * consecutive table rows, scanned FLAT (64 at a time) by closest_hit_fine, with the plane tree as the
-     * guard; NULL unless requested */
+    /* fine leaves: one sphere record (c.xyz, R, Lambda) per HRT_FINE_ROWS consecutive table rows, scanned
+     * FLAT (64 at a time) by closest_hit_fine, with the plane tree as the guard: tables of more than
+     * HRT_FINE_MIN_TRI triangles without the big-table trees; NULL otherwise */
     const float *fine;
     uint32_t num_fine;
 } hrt_kaccel;
 #define HRT_FINE_ROWS 16u
+#define HRT_FINE_MIN_TRI 1024u
 
 /* ---- per-RX direction tables for the shadow rays (host: problem.c; kernels: closest_hit_packet) ----
  * All shadow rays of a trace kind converge on one RX, so which triangles can possibly be met is a

@@ -54,8 +54,8 @@ print("ACCEL_OK", len(cases))
     dict(HRT_NO_TXT="1"),                          # direction tables for the RXs only (default: RXs and TXs)
     dict(HRT_NO_RXT="1"),                          # ... and none at all
     dict(HRT_RXT_MIN_RAYS="67108864"),             # the drop-in's own default: tables from 2^26 rays on (none here)
-    # fine leaves (16 rows) scanned flat + plane tree (opt-in walk), forced onto every table, the table read
-    # from global memory
+    # fine leaves (16 rows) scanned flat + plane tree (the default beyond 1 024 triangles), forced onto every
+    # table, the table read from global memory as there
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0"),
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_SORT_RAYS="1"),
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_NO_REORDER="1"),
@@ -92,13 +92,13 @@ print("CITY_OK", live, "product %%.1f s, oracle %%.1f s" %% (t1 - t0, time.time(
 """
 
 
-@pytest.mark.parametrize("env", [dict(), dict(HRT_ACCEL_FINE_MIN="1024"), dict(HRT_ACCEL_BIG="65536"),
+@pytest.mark.parametrize("env", [dict(), dict(HRT_ACCEL_FINE="0"), dict(HRT_ACCEL_BIG="65536"),
                                  dict(HRT_TRACE_VARIANT="2", HRT_SORT_RAYS="0")],
-                         ids=["default_leaves_resorted", "fine_resorted", "trees_resorted", "flat"])
+                         ids=["default_fine_resorted", "leaves_resorted", "trees_resorted", "flat"])
 def test_city_of_1e5_triangles(env):
-    """10^5 triangles: by default the leaf spheres of 64 rows + guard over a live list re-sorted between
-    bounces; the opt-in fine leaves (16 rows, flat scan) + plane tree; with HRT_ACCEL_BIG lowered the
-    sphere levels + plane tree; and the plain flat walk."""
+    """10^5 triangles: by default the fine leaves (16 rows, flat scan) + plane tree over a live list
+    re-sorted between bounces; the leaf spheres of 64 rows + guard (round 2's default); with
+    HRT_ACCEL_BIG lowered the sphere levels + plane tree; and the plain flat walk."""
     p = subprocess.run([sys.executable, "-c", CITY % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
     assert p.returncode == 0 and "CITY_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
