@@ -1200,9 +1200,28 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
     const Packet P = packet_bounds(B, d, valid, shadow, apex);
     HRT_STAT(kind, 0, 1);
     HRT_STAT(kind, 1, P.usable ? 1 : 0);
-    if (!P.usable) {   // too wide to cull: every triangle, exactly (as the other walks)
+    if (!P.usable) {
+        // Too wide to cull (the rays of the wave scattered off different surfaces): every triangle, exactly.
+        // 64 rows at a time are fetched by the 64 lanes into the wave's LDS buffer and tested from there:
+        // one L2 round trip per 64 triangles -- tested straight from the table the pass is a chain of
+        // dependent loads (~0.5 us per triangle, 12 ms for 25 000), and the 1 % of the packets that take
+        // it were the tail that set the kernel's time.
         HRT_STAT(kind, 2, num_tri);
-        for (uint32_t j = 0; j < num_tri; ++j) HRT_STAGED_BODY(j)
+        float4 *cb = reinterpret_cast<float4 *>(ws) + 2u * kMaskRounds;
+        for (uint32_t base = 0; base < num_tri; base += 64u) {
+            const uint32_t jl = base + lane;
+            if (jl < num_tri) {
+                float4 *slot = cb + 4u * lane;
+                slot[0] = tri[HRT_ROW * jl]; slot[1] = tri[HRT_ROW * jl + 1]; slot[2] = tri[HRT_ROW * jl + 2];
+            }
+            const uint32_t n = min(64u, num_tri - base);
+            for (uint32_t e = 0; e < n; ++e) {
+                const float4 *slot = cb + 4u * e;
+                const float4 c0 = slot[0], c1 = slot[1], c2 = slot[2];
+                const uint32_t j = base + e;
+                HRT_STAGED_TEST(j, c0, c1, c2)
+            }
+        }
         return {who, best};
     }
     unsigned long long *nmask = reinterpret_cast<unsigned long long *>(ws + 16);
@@ -1617,7 +1636,9 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
     const uint32_t k_hi = (b < P.num_bounces) ? P.num_rx + 1u : P.num_rx;
     const uint32_t kinds = k_hi - k_lo;
     // (static deal: chunks padded to a multiple of 8, see the XCD-aware numbering below)
-    const uint32_t n_units = (VARIANT == 6 ? n_chunks : ((n_chunks + 7u) & ~7u)) * kinds;   // < 2^32
+    constexpr bool kPull = (VARIANT == 6);   // units pulled from a counter (uneven unit costs; on the fine walk
+                                             // pulling was measured and lost: 15.7 -> 18.5 ms, the XCD-aware deal matters more)
+    const uint32_t n_units = (kPull ? n_chunks : ((n_chunks + 7u) & ~7u)) * kinds;   // < 2^32
     if (blockIdx.x >= n_units) return;
 
     const uint32_t T = P.num_tri;
@@ -1671,7 +1692,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
     // units of tens of us; on small tables the static deal is cheaper).
     uint32_t *unit_ctr = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + 256u) + b;
     for (uint32_t unit = blockIdx.x;; unit += gridDim.x) {
-        if constexpr (VARIANT == 6) {
+        if constexpr (kPull) {
             if (tid == 0) l_wcnt[0] = atomicAdd(unit_ctr, 1u);
             __syncthreads();
             unit = l_wcnt[0];
@@ -1684,7 +1705,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
         // x = unit % 8: chunk = (q / kinds) * 8 + x, kind = q % kinds (a bijection on the padded range;
         // chunks past the end are skipped).
         uint32_t chunk, k;
-        if constexpr (VARIANT == 6) {
+        if constexpr (kPull) {
             chunk = unit / kinds;
             k = k_lo + (unit - chunk * kinds);
         } else {
