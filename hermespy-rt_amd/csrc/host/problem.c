@@ -436,15 +436,25 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         i_plr = PART(A->pl_rec, (uint64_t)A->pl_num_leaf * 64 * HRT_NODE_FLOATS * 4);
     }
     if (A->fine) i_fine = PART(A->fine, (uint64_t)A->num_fine * HRT_NODE_FLOATS * 4);
+    int i_inv = -1;
+    uint32_t *inv = NULL;
+    if (A->fine) {   /* original index -> row (the wide kernels carry the original index in their keys) */
+        inv = (uint32_t *)malloc((size_t)(T ? T : 1) * 4);
+        if (!inv) { hrt_problem_destroy(p); return hrt_fail(HRT_E_NOMEM, "out of host memory"); }
+        for (uint32_t k = 0; k < (uint32_t)T; ++k) inv[A->orig[k]] = k;
+        i_inv = PART(inv, (uint64_t)(T ? T : 1) * 4);
+    }
 #undef PART
     uint64_t total = 0;
     for (int k = 0; k < np; ++k) { offs[k] = total; total += round_up(len[k] ? len[k] : 1, 256); }
     int rc;
     if ((rc = hrt_hip_set_device(device)) != 0) {
+        free(inv);
         hrt_problem_destroy(p);
         return hrt_fail_hip(rc, "hipSetDevice");
     }
     if ((rc = hrt_hip_malloc(&p->d_blob, total)) != 0) {
+        free(inv);
         p->d_blob = NULL;
         hrt_problem_destroy(p);
         return hrt_fail_hip(rc, "hipMalloc(problem)");
@@ -452,9 +462,11 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
     uint8_t *b = (uint8_t *)p->d_blob;
     for (int k = 0; k < np; ++k)
         if (len[k] && (rc = hrt_hip_h2d(b + offs[k], src[k], len[k]))) {
+            free(inv);
             hrt_problem_destroy(p);
             return hrt_fail_hip(rc, "hipMemcpy(problem)");
         }
+    free(inv);
     p->d_tri = (const float *)(b + offs[i_tri]);
     p->d_mesh = (const float *)(b + offs[i_mesh]);
     p->d_mat = (const float *)(b + offs[i_mat]);
@@ -487,6 +499,8 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
     if (A->fine) {
         ka->fine = (const float *)(b + offs[i_fine]);
         ka->num_fine = A->num_fine;
+        ka->inv = (const uint32_t *)(b + offs[i_inv]);
+        { const char *wc = getenv("HRT_WIDE_COS"); ka->wide_cos = (wc && *wc) ? (float)atof(wc) : HRT_WIDE_COS; }
     }
     {   /* bounding box of the finite vertices (cells of the re-sort keys), and whether to re-sort */
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -846,7 +860,7 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     uint64_t off = 0;
     /* counts[nb + 2], then (from byte 256) one work-unit counter per launch for the trace kernel's
      * dynamic unit distribution on big tables; zeroed together at the start of every trace */
-    L->off_counts = off; off += 512;
+    L->off_counts = off; off += HRT_CNT_BYTES;
     /* survivor counts per super-chunk (HRT_SUPER_CHUNKS chunks of 256 entries) and bounce: directly behind
      * the counts, zeroed with them at the start of every trace */
     L->num_super = cap / HRT_BLOCK / HRT_SUPER_CHUNKS + 1;
@@ -861,7 +875,18 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     L->off_hits = off;   L->hit_block_bytes = (uint64_t)HRT_HIT_FIELDS * cap * 4; off += nb * L->hit_block_bytes;
     L->off_recs = off;   L->rec_block_bytes = (uint64_t)p->num_rx * HRT_REC_FIELDS * cap * 4; off += nb * L->rec_block_bytes;
     L->off_masks = off;  off += round_up(nb * p->num_rx * (cap / 64) * 8, 256);
-    L->off_chunk_cnt = off; off += round_up((cap / HRT_BLOCK + 1) * 4, 256);
+    L->off_chunk_cnt = off; off += round_up((cap / HRT_BLOCK + 1) * 16, 256);   /* one word per wave of a chunk */
+    if (p->accel.fine) {
+        /* the fine walk's queue of wide packets: half the wave-traces of the largest launch (what does
+         * not fit is walked by the pushing wave itself) */
+        const uint64_t traces = (cap / 64) * ((uint64_t)p->num_rx + 1);
+        L->wide_cap = traces / 2 < 1024 ? 1024 : traces / 2;
+        const char *wv = getenv("HRT_WIDE_CAP");
+        if (wv && *wv) L->wide_cap = strtoull(wv, NULL, 10);
+        if (L->wide_cap > 0x7fffffffull / 64) L->wide_cap = 0x7fffffffull / 64;
+        L->off_wide_q = off;   off += round_up(L->wide_cap * 8 + 8, 256);
+        L->off_wide_key = off; off += round_up(L->wide_cap * 64 * 8 + 8, 256);
+    }
     L->off_res = off;    off += ((uint64_t)p->num_rx + 1) * 2 * cap * 4;
     if (p->sort_rays) {
         L->off_sort_scratch = off; off += L->hit_block_bytes;
@@ -1018,6 +1043,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.off_res = L.off_res;
     K.off_lb = L.off_lb;
     K.lb_stride = (uint32_t)L.lb_stride;
+    K.off_wide_q = L.off_wide_q; K.off_wide_key = L.off_wide_key; K.wide_cap = (uint32_t)L.wide_cap;
     K.lb_chunks = (uint32_t)round_up(L.cap / HRT_BLOCK + 1, 64);
     K.fuse = fuse_mode(p);
     if (p->sort_rays) {

@@ -236,6 +236,10 @@ __device__ unsigned long long g_stats[3][HRT_STATS_COLS];
 #ifdef HRT_PHASE_STATS
 __device__ unsigned long long g_phase[65536][8];
 #endif
+#ifdef HRT_UNIT_CLOCKS   // (make EXTRA=-DHRT_UNIT_CLOCKS) one record per wave-trace: start, duration | kind << 56 | usable << 60
+__device__ unsigned long long g_unit[1u << 21][2];
+__device__ unsigned int g_unit_n;
+#endif
 #ifdef HRT_KERNEL_STATS
 #define HRT_STAT(kind, idx, val)                                                      \
     do {                                                                              \
@@ -1167,6 +1171,18 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
     return {who, best};
 }
 
+// The queue of packets that are too wide to cull (closest_hit_fine pushes, hrt_wide_kernel /
+// hrt_wide_finish_kernel consume): an entry is (chunk << 32 | trace kind << 2 | wave of the chunk), its 64
+// keys are the per-ray minima of (float bits of the distance) << 32 | original triangle index.
+constexpr uint32_t HRT_DEFERRED = 0xfffffffeu;   // Hit.tri of a queued packet (wave-uniform)
+struct WideQ {
+    uint32_t *cnt = nullptr;              // entries pushed in this launch (may run past cap: those ran inline)
+    unsigned long long *q = nullptr;
+    unsigned long long *keys = nullptr;
+    uint32_t cap = 0u;
+    unsigned long long entry = 0ull;
+};
+
 // =====================================================================================
 // Acceleration structure, FINE LEAVES (variant 9: the default walk of tables of more than
 // HRT_FINE_MIN_TRI triangles without the big-table trees).  Measured on a city of 25 000 triangles:
@@ -1190,40 +1206,17 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
 template <typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A, uint32_t num_tri, F3 o, F3 d,
                                                 bool valid, uint32_t lane, const Ball &B, const bool shadow, F3 apex,
-                                                unsigned long long *wmask, uint32_t *ws, [[maybe_unused]] int kind)
+                                                unsigned long long *wmask, uint32_t *ws, [[maybe_unused]] int kind,
+                                                const WideQ &wq)
 {
     const uint32_t *__restrict__ orig = A.orig;
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT, who_o = 0u;
     const unsigned long long inval = HRT_BALLOT(!valid);
     if (inval == ~0ull) return {who, best};
-    const Packet P = packet_bounds(B, d, valid, shadow, apex);
+    const Packet P0 = packet_bounds(B, d, valid, shadow, apex);
     HRT_STAT(kind, 0, 1);
-    HRT_STAT(kind, 1, P.usable ? 1 : 0);
-    if (!P.usable) {
-        // Too wide to cull (the rays of the wave scattered off different surfaces): every triangle, exactly.
-        // 64 rows at a time are fetched by the 64 lanes into the wave's LDS buffer and tested from there:
-        // one L2 round trip per 64 triangles -- tested straight from the table the pass is a chain of
-        // dependent loads (~0.5 us per triangle, 12 ms for 25 000), and the 1 % of the packets that take
-        // it were the tail that set the kernel's time.
-        HRT_STAT(kind, 2, num_tri);
-        float4 *cb = reinterpret_cast<float4 *>(ws) + 2u * kMaskRounds;
-        for (uint32_t base = 0; base < num_tri; base += 64u) {
-            const uint32_t jl = base + lane;
-            if (jl < num_tri) {
-                float4 *slot = cb + 4u * lane;
-                slot[0] = tri[HRT_ROW * jl]; slot[1] = tri[HRT_ROW * jl + 1]; slot[2] = tri[HRT_ROW * jl + 2];
-            }
-            const uint32_t n = min(64u, num_tri - base);
-            for (uint32_t e = 0; e < n; ++e) {
-                const float4 *slot = cb + 4u * e;
-                const float4 c0 = slot[0], c1 = slot[1], c2 = slot[2];
-                const uint32_t j = base + e;
-                HRT_STAGED_TEST(j, c0, c1, c2)
-            }
-        }
-        return {who, best};
-    }
+    HRT_STAT(kind, 1, P0.usable ? 1 : 0);
     unsigned long long *nmask = reinterpret_cast<unsigned long long *>(ws + 16);
     uint32_t *nbase = ws + 24;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -1255,6 +1248,51 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
         }
         nbuf += n;
     };
+    // A packet too wide to cull (the rays of the wave scattered off different surfaces; 0.1-0.3 % of the
+    // packets after the re-sort) owes every triangle an exact test: a serial chain of T staged tests in
+    // ONE wave (4 ms for 25 000 triangles, 16 ms for 100 000) -- few as they are, those passes were the
+    // TAIL that set the kernel's time (0.9 resident waves per SIMD on average, profiles/unit_clocks.py).
+    // The wave therefore only QUEUES the packet (hrt_wide): hrt_wide_kernel spreads (packet, slice of the
+    // table) items over the whole chip and merges the per-ray minima of (distance, original index) with
+    // 64-bit atomic minima, hrt_wide_finish_kernel writes the results.  Only when the queue is full does the
+    // wave run the pass itself.
+    const Packet &P = P0;
+#ifdef HRT_UNIT_CLOCKS
+    if (lane == 0) { ws[15] = P0.usable ? 1u : 0u; ws[14] = 0u; ws[13] = (uint32_t)(fmaxf(P0.cosa, 0.f) * 255.f); ws[12] = 0u; }
+#endif
+    const bool wide = !P0.usable || !(P0.cosa >= A.wide_cos);
+    if (wide) {
+        uint32_t slot = 0xffffffffu;
+        if (wq.cnt != nullptr) {
+            if (lane == 0) slot = atomicAdd(wq.cnt, 1u);
+            slot = uni(slot);
+        }
+        if (slot < wq.cap) {
+            if (lane == 0) wq.q[slot] = wq.entry;
+            wq.keys[(uint64_t)slot * 64u + lane] = ~0ull;
+            return {HRT_DEFERRED, best};
+        }
+    }
+    if (!P0.usable) {
+        // (queue full) every triangle, exactly: 64 rows at a time are fetched by the 64 lanes into the wave's
+        // LDS buffer and tested from there (one L2 round trip per 64 triangles)
+        HRT_STAT(kind, 2, num_tri);
+        for (uint32_t base = 0; base < num_tri; base += 64u) {
+            const uint32_t jl = base + lane;
+            if (jl < num_tri) {
+                float4 *slot4 = cbuf + 4u * lane;
+                slot4[0] = tri[HRT_ROW * jl]; slot4[1] = tri[HRT_ROW * jl + 1]; slot4[2] = tri[HRT_ROW * jl + 2];
+            }
+            const uint32_t n = min(64u, num_tri - base);
+            for (uint32_t e = 0; e < n; ++e) {
+                const float4 *slot4 = cbuf + 4u * e;
+                const float4 c0 = slot4[0], c1 = slot4[1], c2 = slot4[2];
+                const uint32_t j = base + e;
+                HRT_STAGED_TEST(j, c0, c1, c2)
+            }
+        }
+        return {who, best};
+    }
     // ---- fine leaves, flat: lane l looks at sphere base + l ----
     {
         const float4 *fine = reinterpret_cast<const float4 *>(A.fine);
@@ -1268,6 +1306,9 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
             const bool far = f.m > fmaxf(0.5f * n1.x, kMu * f.S);   // NaN / inf: not far
             unsigned long long near = HRT_BALLOT(has && !far);
             HRT_STAT(kind, 8, 1);
+#ifdef HRT_UNIT_CLOCKS
+            if (lane == 0) ws[14] += (uint32_t)__popcll(near);
+#endif
             while (near) {   // the rows of four near spheres make one culling round
                 uint32_t s4[4];
 #pragma unroll
@@ -1331,6 +1372,9 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
                 const float4 r0 = rec[0], r1 = rec[1];
                 bool cand = j != HRT_NO_HIT;
                 HRT_STAT(kind, 10, 1);
+#ifdef HRT_UNIT_CLOCKS
+                if (lane == 0) ws[12] += 1u;
+#endif
                 if (cand) {
                     const F3 n = {r1.x, r1.y, r1.z};
                     const float amin = __builtin_fmaf(fabsf(fdot3(P.ax, n)), P.cosa, -P.sina);
@@ -1378,7 +1422,7 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, c
                                            const uint32_t *__restrict__ orig, uint32_t num_tri, F3 o,
                                            F3 d, bool valid, uint32_t lane, const Ball &B,
                                            const bool shadow, F3 apex, unsigned long long *wmask,
-                                           float4 *wleaf, int kind)
+                                           float4 *wleaf, int kind, const WideQ &wq = WideQ{})
 {
     if constexpr (VARIANT == 0) {
         Hit h = {HRT_NO_HIT, 1e9f};
@@ -1396,7 +1440,7 @@ __device__ __forceinline__ Hit closest_hit(TriPtr tri, TgPtr tg, LeafPtr leaf, c
                                reinterpret_cast<uint32_t *>(wleaf), kind);
     } else if constexpr (VARIANT == 9) {
         return closest_hit_fine(tri, A, num_tri, o, d, valid, lane, B, shadow, apex, wmask,
-                                reinterpret_cast<uint32_t *>(wleaf), kind);
+                                reinterpret_cast<uint32_t *>(wleaf), kind, wq);
     } else {
         return closest_hit_tree<(VARIANT == 5)>(tri, tg, leaf, orig, num_tri, o, d, valid, lane, B, shadow,
                                                 apex, wmask, wleaf, kind);
@@ -1690,7 +1734,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
     // trace can cost a hundred times another (a wave whose rays scattered is walked ray by ray):
     // there the workgroups pull units from a counter (one returning atomic per unit: ~1 us against
     // units of tens of us; on small tables the static deal is cheaper).
-    uint32_t *unit_ctr = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + 256u) + b;
+    uint32_t *unit_ctr = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + HRT_CNT_UNITS) + b;
     for (uint32_t unit = blockIdx.x;; unit += gridDim.x) {
         if constexpr (kPull) {
             if (tid == 0) l_wcnt[0] = atomicAdd(unit_ctr, 1u);
@@ -1755,13 +1799,38 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
         if constexpr (VARIANT >= 2 && VARIANT != 6)
             if (!masked) ball = origin_ball(o, valid);
+        WideQ wq;
+        if constexpr (VARIANT == 9) {
+            if (P.wide_cap != 0u) {
+                wq.cnt = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + HRT_CNT_WIDE) + b;
+                wq.q = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_q);
+                wq.keys = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_key);
+                wq.cap = P.wide_cap;
+                wq.entry = ((unsigned long long)chunk << 32) | ((unsigned long long)k << 2) | (tid >> 6);
+            }
+        }
 #ifdef HRT_KERNEL_STATS
         const long long t_unit0 = clock64();
+#endif
+#ifdef HRT_UNIT_CLOCKS
+        const unsigned long long t_w0 = wall_clock64();
 #endif
         const Hit h = masked ? closest_hit_masked(tri, P.acc.orig, P.rxt, shadow ? k : P.num_rx + tx_lane, T, o, d, valid,
                                                   lane, shadow ? 2 : 0)
                              : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane,
-                                                    ball, shadow, apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1));
+                                                    ball, shadow, apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1), wq);
+#ifdef HRT_UNIT_CLOCKS
+        if (lane == 0) {
+            const unsigned long long dt = wall_clock64() - t_w0;
+            const unsigned int slot = atomicAdd(&g_unit_n, 1u) & ((1u << 21) - 1u);
+            g_unit[slot][0] = t_w0;
+            g_unit[slot][1] = dt | ((unsigned long long)(shadow ? 2 : (first ? 0 : 1)) << 56) |
+                              ((unsigned long long)(reinterpret_cast<uint32_t *>(l_wleaf)[15] & 1u) << 60) |
+                              ((unsigned long long)min(reinterpret_cast<uint32_t *>(l_wleaf)[14], 0xfffu) << 32) |
+                              ((unsigned long long)min(reinterpret_cast<uint32_t *>(l_wleaf)[12], 0xfffu) << 44) |
+                              ((unsigned long long)(reinterpret_cast<uint32_t *>(l_wleaf)[13] & 0xffu) << 24);
+        }
+#endif
 #ifdef HRT_KERNEL_STATS
         if (lane == 0) {   // per wave-trace: longest and total duration in shader clocks
             const unsigned long long dt = (unsigned long long)(clock64() - t_unit0);
@@ -1769,7 +1838,9 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
             atomicAdd(&g_stats[shadow ? 2 : (first ? 0 : 1)][14], dt);
         }
 #endif
-        if (valid) {
+        // (a packet queued for the wide kernels: results and survivor count are hrt_wide_finish_kernel's)
+        const bool deferred = VARIANT == 9 && h.tri == HRT_DEFERRED;
+        if (valid && !deferred) {
             // a shadow trace is consumed as "which triangle (for the incidence angle), and is it
             // within 1 m (the reference's blocking test, quirk Q6)": one word, bit 31 = blocked,
             // 0x7fffffff = nothing hit; the bounce itself needs triangle and distance
@@ -1790,19 +1861,286 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
         // the bounce itself: how many rays of this chunk survive.  With the counts of all chunks
         // known BEFORE the shade kernel runs, that kernel can write every survivor straight to
         // its final place in the next live list (stable compaction without a staging copy).
-        if (!shadow) {
+        // (one word per WAVE of the chunk: the sum is the shade kernel's)
+        if constexpr (VARIANT == 9) {
+            // big tables: one trace can cost a hundred times another, so the four waves of a workgroup do
+            // not wait for each other between units -- each publishes its own count
+            if (!shadow && !deferred) {
+                const unsigned long long hm = __ballot(valid && h.tri != HRT_NO_HIT);
+                if (lane == 0) {
+                    const uint32_t c = (uint32_t)__popcll(hm);
+                    reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk * 4u + (tid >> 6)] = c;
+                    atomicAdd(reinterpret_cast<uint32_t *>(P.ws + P.off_super_cnt) +
+                                  (uint64_t)b * P.num_super + (chunk >> HRT_SUPER_SHIFT), c);
+                }
+            }
+        } else if (!shadow) {
             const unsigned long long hm = __ballot(valid && h.tri != HRT_NO_HIT);
             if (lane == 0) l_wcnt[tid >> 6] = (uint32_t)__popcll(hm);
             __syncthreads();
             if (tid == 0) {
                 const uint32_t c = l_wcnt[0] + l_wcnt[1] + l_wcnt[2] + l_wcnt[3];
-                reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] = c;
+                reinterpret_cast<uint4 *>(P.ws + P.off_chunk_cnt)[chunk] = make_uint4(c, 0u, 0u, 0u);
                 // ... and the sum over every HRT_SUPER_CHUNKS chunks ("super-chunk"): two short sums in the
                 // shade kernel then replace a scan pass over all chunks
                 atomicAdd(reinterpret_cast<uint32_t *>(P.ws + P.off_super_cnt) +
                               (uint64_t)b * P.num_super + (chunk >> HRT_SUPER_SHIFT), c);
             }
             __syncthreads();
+        }
+    }
+}
+
+// ===================================================================================
+// WIDE kernels (big tables, behind the trace kernel of the fine walk): the packets that were too wide to
+// cull -- 0.1-0.3 % of a launch after the re-sort, each owing EVERY triangle the exact staged test.
+// hrt_wide_kernel: item = (queue entry, slice of HRT_WIDE_SLICE table rows), dealt statically to the waves
+// of a fixed grid, slice-major (the waves working at one time share a slice: its rows stay in L2); a wave
+// re-creates the 64 rays exactly as the trace kernel does, fetches the slice 64 rows at a time into its LDS
+// buffer, runs the staged test and merges its per-ray minimum of (distance, ORIGINAL index) -- the tie
+// rule of every walk -- into the entry's keys with a 64-bit atomic minimum (distances are positive floats:
+// their bit patterns order like the values).  hrt_wide_finish_kernel: one wave per entry turns the keys into
+// the trace kernel's result words and the wave's survivor count.
+// ===================================================================================
+__device__ __forceinline__ void wide_entry_ray(const hrt_kparams &P, const uint32_t b, const unsigned long long entry,
+                                               const uint32_t lane, const uint32_t n_in, uint32_t &chunk, uint32_t &k,
+                                               uint32_t &wv, uint32_t &i, bool &valid, bool &shadow, F3 &o, F3 &d)
+{
+    chunk = (uint32_t)(entry >> 32);
+    k = ((uint32_t)entry) >> 2;
+    wv = ((uint32_t)entry) & 3u;
+    i = chunk * HRT_BLOCK + wv * 64u + lane;
+    valid = i < n_in;
+    shadow = k < P.num_rx;
+    const uint32_t cap4 = (uint32_t)P.cap * 4u, i4 = i * 4u;
+    o = {0.f, 0.f, 0.f};
+    d = {0.f, 0.f, 1.f};
+    if (valid) {
+        if (b == 0) {
+            uint32_t ray, tx_lane;
+            launch_ray(P, i, ray, o, d, tx_lane);
+        } else {
+            const uint32_t pb = b - 1;
+            o = {ldf(hit_blk(P, pb), H_OX * cap4, i4), ldf(hit_blk(P, pb), H_OY * cap4, i4),
+                 ldf(hit_blk(P, pb), H_OZ * cap4, i4)};
+            if (!shadow)
+                d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4),
+                     ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
+        }
+    }
+    if (shadow) {
+        float d2rx;
+        const F3 w = shadow_dir(o, {P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2]}, d2rx);
+        if (valid) d = w;
+    }
+}
+
+constexpr uint32_t kWideGrid = 2048u;   // workgroups of hrt_wide_kernel (4 waves each)
+static_assert(HRT_WIDE_SLICE == 64u * HRT_FINE_ROWS, "a slice is one round of fine spheres");
+
+// A slice of a USABLE packet (one that was queued because its cone is wide: its walk would take
+// milliseconds in one wave) is culled like the fine walk culls -- the slice's 64 fine spheres in one round,
+// the rows of near spheres through packet_culls -- but without the plane tree: the rows of the FAR spheres
+// are looked at one by one (64 per round): a triangle that is not nearly parallel to the rays
+// (|d.n| > Gamma_i for every ray) is rejected by the lemma's first term (DESIGN_ACCEL.md B.4), any other
+// is judged by its own ball (p1, l) exactly as the plane tree's leaves judge theirs, and what is not
+// cleared is packet-tested and, if it survives, staged-tested.
+__global__ __launch_bounds__(HRT_BLOCK) void hrt_wide_kernel(const hrt_kparams P, const uint32_t b)
+{
+    __shared__ float4 l_rows[HRT_BLOCK / 64u][kCandBuf * 4u];
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    const uint32_t nq = min(reinterpret_cast<const uint32_t *>(P.ws + P.off_counts + HRT_CNT_WIDE)[b], P.wide_cap);
+    if (nq == 0u) return;
+    const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
+    const uint32_t T = P.num_tri;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const float4 *__restrict__ tri = reinterpret_cast<const float4 *>(P.tri);
+    const float2 *__restrict__ tg = reinterpret_cast<const float2 *>(P.acc.tg);
+    const float4 *__restrict__ fine = reinterpret_cast<const float4 *>(P.acc.fine);
+    const uint32_t *__restrict__ orig = P.acc.orig;
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(P.ws + P.off_wide_q);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_key);
+    float4 *cbuf = l_rows[wave];
+    const uint64_t n_slices = ((uint64_t)T + HRT_WIDE_SLICE - 1u) / HRT_WIDE_SLICE;
+    const uint64_t n_items = n_slices * nq;
+    const bool cull = !(P.acc.dbg & 16u);   // (HRT_ACCEL_DEBUG bit 4: every slice flat, timing experiments)
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    [[maybe_unused]] const int kind = 1;
+    for (uint64_t item = (uint64_t)blockIdx.x * (HRT_BLOCK / 64u) + wave; item < n_items;
+         item += (uint64_t)gridDim.x * (HRT_BLOCK / 64u)) {
+        const uint32_t slice = (uint32_t)(item / nq), e = (uint32_t)(item - (uint64_t)slice * nq);
+        uint32_t chunk, k, wv, i;
+        bool valid, shadow;
+        F3 o, d;
+        wide_entry_ray(P, b, q[e], lane, n_in, chunk, k, wv, i, valid, shadow, o, d);
+        const unsigned long long inval = HRT_BALLOT(!valid);
+        float best = 1e9f;
+        uint32_t who = HRT_NO_HIT, who_o = 0u;
+        const uint32_t row0 = slice * HRT_WIDE_SLICE, row1 = min(T, row0 + HRT_WIDE_SLICE);
+        Packet Pk;
+        Pk.usable = false;
+        if (cull) {
+            const Ball B = origin_ball(o, valid);
+            F3 apex = {0.f, 0.f, 0.f};
+            if (shadow) apex = {P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2]};
+            Pk = packet_bounds(B, d, valid, shadow, apex);
+        }
+        if (Pk.usable) {
+            uint32_t nbuf = 0u;
+            auto flush = [&]() {
+                for (uint32_t t = 0; t < nbuf; ++t) {
+                    const float4 *slot = cbuf + 4u * t;
+                    const float4 c0 = slot[0], c1 = slot[1], c2 = slot[2];
+                    const uint32_t j = uni(__float_as_uint(slot[3].x));
+                    HRT_STAGED_TEST(j, c0, c1, c2)
+                }
+                nbuf = 0u;
+            };
+            auto park = [&](bool cand, uint32_t j, float4 c0, float4 c1, float4 c2) {   // all lanes call (uniform)
+                const unsigned long long cm = HRT_BALLOT(cand);
+                const uint32_t n = (uint32_t)__popcll(cm);
+                if (n == 0u) return;
+                if (nbuf + n > kCandBuf) flush();
+                if (cand) {
+                    float4 *slot = cbuf + 4u * (nbuf + lane_prefix(cm));
+                    slot[0] = c0; slot[1] = c1; slot[2] = c2;
+                    slot[3] = make_float4(__uint_as_float(j), 0.f, 0.f, 0.f);
+                }
+                nbuf += n;
+            };
+            const uint32_t s0 = row0 / HRT_FINE_ROWS;
+            const uint32_t idx = s0 + lane;
+            const bool has = idx < P.acc.num_fine;
+            const uint32_t ic = has ? idx : s0;
+            const float4 n0 = fine[2u * ic], n1 = fine[2u * ic + 1u];
+            const LeafFar f = leaf_far(Pk, n0, n1);
+            const bool far = f.m > fmaxf(0.5f * n1.x, kMu * f.S);   // NaN / inf: not far
+            unsigned long long near = HRT_BALLOT(has && !far), farm = HRT_BALLOT(has && far);
+            const uint32_t g = lane >> 4;
+            while (near) {   // the rows of four near spheres make one culling round
+                uint32_t s4[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    s4[qq] = HRT_NO_HIT;
+                    if (near) {
+                        s4[qq] = s0 + (uint32_t)__builtin_ctzll(near);
+                        near &= near - 1ull;
+                    }
+                }
+                const uint32_t mine = g == 0u ? s4[0] : (g == 1u ? s4[1] : (g == 2u ? s4[2] : s4[3]));
+                const uint32_t jl = mine * HRT_FINE_ROWS + (lane & 15u);
+                bool cand = mine != HRT_NO_HIT && jl < T;
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
+                if (cand) {
+                    c0 = tri[HRT_ROW * jl]; c1 = tri[HRT_ROW * jl + 1]; c2 = tri[HRT_ROW * jl + 2];
+                    cand = !packet_culls(Pk, c0, c1, c2, tri[HRT_ROW * jl + 3], tri[HRT_ROW * jl + 4]);
+                }
+                park(cand, jl, c0, c1, c2);
+            }
+            while (farm) {   // the rows of four far spheres: the guard, triangle by triangle
+                uint32_t s4[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    s4[qq] = HRT_NO_HIT;
+                    if (farm) {
+                        s4[qq] = s0 + (uint32_t)__builtin_ctzll(farm);
+                        farm &= farm - 1ull;
+                    }
+                }
+                const uint32_t mine = g == 0u ? s4[0] : (g == 1u ? s4[1] : (g == 2u ? s4[2] : s4[3]));
+                const uint32_t jl = mine * HRT_FINE_ROWS + (lane & 15u);
+                bool cand = mine != HRT_NO_HIT && jl < T;
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c2 = c0;
+                if (cand) {
+                    c0 = tri[HRT_ROW * jl]; c2 = tri[HRT_ROW * jl + 2];
+                    const float2 gq = tg[jl];   // qs, longest edge
+                    const F3 n = {c2.y, c2.z, c2.w};
+                    const float amin = __builtin_fmaf(fabsf(fdot3(Pk.ax, n)), Pk.cosa, -Pk.sina);
+                    bool safe = amin > kGammaPerQs * gq.x;           // the sphere vouches for it
+                    if (!safe) {
+                        const LeafFar fb = leaf_far(Pk, make_float4(c0.x, c0.y, c0.z, gq.y), make_float4(gq.y, 0.f, 0.f, 0.f));
+                        const F3 sb = sub3(Pk.bc, {c0.x, c0.y, c0.z});
+                        const float hmin = fabsf(fdot3(n, sb)) - Pk.br * 1.0001f -
+                                           2e-6f * ((fabsf(sb.x) + fabsf(sb.y)) + fabsf(sb.z));
+                        const float Ti = gq.x * (fb.S + gq.y);
+                        safe = (fb.m > 0.f) & ((amin * fb.phi > Ti) | (hmin * fb.kappa > Ti));
+                    }
+                    cand = !safe;
+                }
+                if (HRT_BALLOT(cand) != 0ull) {
+                    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cand) {
+                        c1 = tri[HRT_ROW * jl + 1];
+                        cand = !packet_culls(Pk, c0, c1, c2, tri[HRT_ROW * jl + 3], tri[HRT_ROW * jl + 4]);
+                    }
+                    park(cand, jl, c0, c1, c2);
+                }
+            }
+            flush();
+        } else {
+            for (uint32_t base = row0; base < row1; base += 64u) {
+                const uint32_t jl = base + lane;
+                if (jl < row1) {
+                    cbuf[3u * lane] = tri[HRT_ROW * jl];
+                    cbuf[3u * lane + 1u] = tri[HRT_ROW * jl + 1];
+                    cbuf[3u * lane + 2u] = tri[HRT_ROW * jl + 2];
+                }
+                const uint32_t n = min(64u, row1 - base);
+                for (uint32_t t = 0; t < n; ++t) {
+                    const float4 c0 = cbuf[3u * t], c1 = cbuf[3u * t + 1u], c2 = cbuf[3u * t + 2u];
+                    const uint32_t j = base + t;
+                    HRT_STAGED_TEST(j, c0, c1, c2)
+                }
+            }
+        }
+        if (valid && who != HRT_NO_HIT)
+            atomicMin(keys + (uint64_t)e * 64u + lane, ((unsigned long long)__float_as_uint(best) << 32) | who_o);
+    }
+}
+
+__global__ __launch_bounds__(HRT_BLOCK) void hrt_wide_finish_kernel(const hrt_kparams P, const uint32_t b)
+{
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    const uint32_t nq = min(reinterpret_cast<const uint32_t *>(P.ws + P.off_counts + HRT_CNT_WIDE)[b], P.wide_cap);
+    const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
+    const uint32_t T = P.num_tri;
+    const uint32_t cap4 = (uint32_t)P.cap * 4u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(P.ws + P.off_wide_q);
+    const unsigned long long *keys = reinterpret_cast<const unsigned long long *>(P.ws + P.off_wide_key);
+    for (uint32_t e = blockIdx.x * (HRT_BLOCK / 64u) + wave; e < nq; e += gridDim.x * (HRT_BLOCK / 64u)) {
+        const unsigned long long entry = q[e];
+        const uint32_t chunk = (uint32_t)(entry >> 32), k = ((uint32_t)entry) >> 2, wv = ((uint32_t)entry) & 3u;
+        const uint32_t i = chunk * HRT_BLOCK + wv * 64u + lane, i4 = i * 4u;
+        const bool valid = i < n_in, shadow = k < P.num_rx;
+        const unsigned long long key = keys[(uint64_t)e * 64u + lane];
+        Hit h = {HRT_NO_HIT, 1e9f};
+        if (key != ~0ull) {
+            h.tri = P.acc.inv[(uint32_t)key];
+            h.t = __uint_as_float((uint32_t)(key >> 32));
+        }
+        if (valid) {   // (the trace kernel's result words)
+            if (shadow) {
+                if (T < HRT_HALF_RESULTS_MAX) {
+                    const uint32_t code16 = (h.tri == HRT_NO_HIT) ? 0x7fffu : (h.tri | ((h.t <= 1.f) ? 0x8000u : 0u));
+                    __builtin_amdgcn_raw_buffer_store_b16((short)code16, res_blk(P, k), (int)(i * 2u), 0, 0);
+                } else {
+                    const uint32_t code = (h.tri == HRT_NO_HIT) ? 0x7fffffffu : (h.tri | ((h.t <= 1.f) ? 0x80000000u : 0u));
+                    stu(res_blk(P, k), 0u, i4, code);
+                }
+            } else {
+                stu(res_blk(P, k), 0u, i4, h.tri);
+                stf(res_blk(P, k), cap4, i4, h.t);
+            }
+        }
+        if (!shadow) {
+            const unsigned long long hm = __ballot(valid && h.tri != HRT_NO_HIT);
+            if (lane == 0) {
+                const uint32_t c = (uint32_t)__popcll(hm);
+                reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk * 4u + wv] = c;
+                atomicAdd(reinterpret_cast<uint32_t *>(P.ws + P.off_super_cnt) +
+                              (uint64_t)b * P.num_super + (chunk >> HRT_SUPER_SHIFT), c);
+            }
         }
     }
 }
@@ -2065,8 +2403,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                 const uint32_t n_sup =
                     (chunk == 0) ? ((n_in + HRT_BLOCK - 1) / HRT_BLOCK + HRT_SUPER_CHUNKS - 1u) >> HRT_SUPER_SHIFT : sup;
                 for (uint32_t q = tid; q < n_sup; q += HRT_BLOCK) part += scnt[q];
-                const uint32_t c = (sup << HRT_SUPER_SHIFT) + tid;
-                if (chunk != 0 && tid < HRT_SUPER_CHUNKS && c < chunk) part += ccnt[c];
+                const uint32_t cw = ((sup << HRT_SUPER_SHIFT) << 2) + tid;   // one word per wave of a chunk
+                if (chunk != 0 && tid < 4u * HRT_SUPER_CHUNKS && (cw >> 2) < chunk) part += ccnt[cw];
             }
             part = wave_sum_u32(part);
             const unsigned long long m = __ballot(hit);
@@ -3305,8 +3643,13 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
     const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
     // fine leaves + plane tree where the host built them (beyond HRT_FINE_MIN_TRI triangles): auto, or variant 9
     const bool fine = !in_lds && !trees && P->acc.fine != nullptr && (variant == 7 || variant == 9);
-    if (fine) launch_trace_t<false, 9>(P, bounce, nb, lds, st, &err);
-    else if (in_lds) {
+    if (fine) {
+        launch_trace_t<false, 9>(P, bounce, nb, lds, st, &err);
+        if (err == hipSuccess && P->wide_cap != 0u) {   // the packets the walk queued as too wide to cull
+            hipLaunchKernelGGL(hrt_wide_kernel, dim3(kWideGrid), dim3(HRT_BLOCK), 0, st, *P, bounce);
+            hipLaunchKernelGGL(hrt_wide_finish_kernel, dim3(256), dim3(HRT_BLOCK), 0, st, *P, bounce);
+        }
+    } else if (in_lds) {
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
         else if (flat) {
@@ -3495,6 +3838,18 @@ int hrt_hip_read_stats(unsigned long long *out, int reset)
         if (hipMemcpyFromSymbol(host_phase, HIP_SYMBOL(g_phase), sizeof host_phase) == hipSuccess) {
             if (FILE *f = fopen(pf, "wb")) { fwrite(host_phase, 1, sizeof host_phase, f); fclose(f); }
         }
+    }
+#endif
+#ifdef HRT_UNIT_CLOCKS
+    if (const char *uf = getenv("HRT_UNIT_FILE")) {
+        static unsigned long long host_unit[1u << 21][2];
+        unsigned int n = 0;
+        if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_unit_n), sizeof n) == hipSuccess &&
+            hipMemcpyFromSymbol(host_unit, HIP_SYMBOL(g_unit), sizeof host_unit) == hipSuccess) {
+            if (n > (1u << 21)) n = 1u << 21;
+            if (FILE *f = fopen(uf, "wb")) { fwrite(host_unit, 16, n, f); fclose(f); }
+        }
+        if (reset) { n = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_n), &n, sizeof n); }
     }
 #endif
 #if defined(HRT_KERNEL_STATS) || defined(HRT_PHASE_STATS)

@@ -62,9 +62,14 @@ typedef struct {
      * HRT_FINE_MIN_TRI triangles without the big-table trees; NULL otherwise */
     const float *fine;
     uint32_t num_fine;
+    const uint32_t *inv;            /* [T] index in the reference's loop order -> table row (the inverse of orig) */
+    float wide_cos;                 /* fine walk: packets whose cone is wider than this cosine go to the wide kernels */
 } hrt_kaccel;
 #define HRT_FINE_ROWS 16u
 #define HRT_FINE_MIN_TRI 1024u
+#define HRT_WIDE_COS 0.995f    /* half-angle 5.7 deg.  Measured (ms per step, 3 M rays; city 25 k / 100 k, room 24 k):
+                                * 0.5 15.4 / 56.7 / 22.2, 0.95 8.4 / 31.7 / 10.9, 0.99 7.5 / 27.8 / 11.0, 0.995 7.2 / 26.4,
+                                * 0.999 7.0 / 25.0 / 11.5, every packet 10.7 / 38.2 / 16.6 */
 
 /* ---- per-RX direction tables for the shadow rays (host: problem.c; kernels: closest_hit_packet) ----
  * All shadow rays of a trace kind converge on one RX, so which triangles can possibly be met is a
@@ -148,7 +153,19 @@ typedef struct {
     uint32_t los_blocks;  /* fused launch 0: the last los_blocks workgroups of the grid do the LoS pass (0: own kernel) */
     uint32_t phase_bounce;   /* -DHRT_PHASE_STATS builds: the launch whose workgroups record their time stamps */
     uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
+    /* queue of the packets that are too wide to cull (big tables, hrt_wide_kernel): wide_cap entries of
+     * 8 bytes at off_wide_q, 64 keys of 8 bytes per entry at off_wide_key; the per-launch entry counts are
+     * the u32 at off_counts + HRT_CNT_WIDE + 4 b (zeroed with the counts).  wide_cap 0: no queue */
+    uint64_t off_wide_q, off_wide_key;
+    uint32_t wide_cap;
 } hrt_kparams;
+
+/* the counter block at off_counts (HRT_CNT_BYTES, zeroed at the start of every trace): counts[nb + 2] |
+ * one work-unit counter per launch (trees) | one wide-queue entry count per launch */
+#define HRT_CNT_UNITS 256u
+#define HRT_CNT_WIDE 512u
+#define HRT_CNT_BYTES 1024u
+#define HRT_WIDE_SLICE 1024u  /* table rows of one (packet, slice) item of hrt_wide_kernel: 64 fine spheres */
 
 /* hrt_kparams.fuse */
 #define HRT_FUSE_LAUNCH0 1u   /* launch 0 (no shadow rays, state generated in registers) */
@@ -173,6 +190,7 @@ int hrt_hip_mem_info(uint64_t *free_b, uint64_t *total_b);
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream);
 int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
+
 int hrt_hip_launch_fused(const hrt_kparams *P, uint32_t bounce, void *stream);   /* -1: not fusable, nothing launched */
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,

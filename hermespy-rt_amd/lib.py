@@ -42,7 +42,7 @@ class Layout(C.Structure):
         "total_bytes", "cap", "off_counts", "off_los", "off_hits", "hit_block_bytes",
         "off_recs", "rec_block_bytes", "off_masks", "off_chunk_cnt", "off_super_cnt", "off_res",
         "num_super", "off_sort_scratch", "off_sort_keys", "off_sort_tmp", "sort_tmp_bytes",
-        "off_lb", "lb_stride")]
+        "off_lb", "lb_stride", "off_wide_q", "off_wide_key", "wide_cap")]
 
 
 class KernelTimes(C.Structure):

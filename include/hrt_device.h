@@ -148,7 +148,7 @@ typedef struct {
                                                        + (rx*HRT_REC_FIELDS + f)*cap*4 */
     uint64_t rec_block_bytes;
     uint64_t off_masks;         /* u64 words of (b, rx) at off_masks + (b*num_rx + rx)*(cap/64)*8 */
-    /* scratch of the stable compaction: survivor counts per 256-entry chunk, and per bounce the
+    /* scratch of the stable compaction: survivor counts per WAVE of every 256-entry chunk (4 u32 per chunk), and per bounce the
      * sums over every 32 chunks (u32 [num_bounces][num_super]) */
     uint64_t off_chunk_cnt, off_super_cnt;
     /* trace results of one launch (internal scratch between the two kernels): for trace kind k
@@ -165,6 +165,9 @@ typedef struct {
      * and per-supergroup survivor counts): u32 [num_bounces + 1][lb_stride], zeroed with the counts
      * at the start of every trace */
     uint64_t off_lb, lb_stride;
+    /* queue of the packets too wide to cull (tables of more than 1 024 triangles): wide_cap entries of
+     * 8 bytes, then 64 keys of 8 bytes per entry; wide_cap = 0: none */
+    uint64_t off_wide_q, off_wide_key, wide_cap;
 } hrt_layout;
 
 /* HRT_E_CAPACITY when num_tx * (local rays) exceeds 2^32 / (HRT_HIT_FIELDS * 4) - 512

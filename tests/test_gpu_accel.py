@@ -59,8 +59,13 @@ print("ACCEL_OK", len(cases))
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0"),
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_SORT_RAYS="1"),
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_NO_REORDER="1"),
+    # ... its queue of too-wide packets (hrt_wide_kernel) overflowing after 3 entries (the rest runs in the
+    # pushing wave), and absent
+    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_WIDE_CAP="3"),
+    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_WIDE_CAP="0", HRT_SORT_RAYS="1"),
 ], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order",
-        "rx_tables_only", "no_tables", "tables_by_size", "fine", "fine_resort", "fine_ref_order"])
+        "rx_tables_only", "no_tables", "tables_by_size", "fine", "fine_resort", "fine_ref_order", "fine_queue_overflow",
+        "fine_no_queue"])
 def test_modes_are_bit_identical_to_the_oracle(env):
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
@@ -92,9 +97,9 @@ print("CITY_OK", live, "product %%.1f s, oracle %%.1f s" %% (t1 - t0, time.time(
 """
 
 
-@pytest.mark.parametrize("env", [dict(), dict(HRT_ACCEL_FINE="0"), dict(HRT_ACCEL_BIG="65536"),
+@pytest.mark.parametrize("env", [dict(), dict(HRT_WIDE_CAP="40"), dict(HRT_ACCEL_FINE="0"), dict(HRT_ACCEL_BIG="65536"),
                                  dict(HRT_TRACE_VARIANT="2", HRT_SORT_RAYS="0")],
-                         ids=["default_fine_resorted", "leaves_resorted", "trees_resorted", "flat"])
+                         ids=["default_fine_resorted", "fine_queue_overflow", "leaves_resorted", "trees_resorted", "flat"])
 def test_city_of_1e5_triangles(env):
     """10^5 triangles: by default the fine leaves (16 rows, flat scan) + plane tree over a live list
     re-sorted between bounces; the leaf spheres of 64 rows + guard (round 2's default); with
