@@ -1119,6 +1119,10 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
         const int fused = b == 0 ? (K.fuse & HRT_FUSE_LAUNCH0) != 0 : (K.fuse & HRT_FUSE_BOUNCES) != 0;
         int fused_rc = -1;
         if (fused && !hip) fused_rc = hrt_hip_launch_fused(&K, b, stream);   /* -1: this table / variant is not fusable */
+        if (fused_rc < 0 && b == 0 && K.los_blocks) {   /* launch 0 is not fused after all: the LoS pass as its own kernel */
+            K.los_blocks = 0u;
+            STEP(hrt_hip_launch_los(&K, stream));
+        }
         if (fused_rc >= 0) {
             STEP(fused_rc);
             if (ev) STEP(hrt_hip_event_record(ev[3 + 4 * b], stream));

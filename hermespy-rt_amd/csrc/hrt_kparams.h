@@ -67,7 +67,7 @@ typedef struct {
 } hrt_kaccel;
 #define HRT_FINE_ROWS 16u
 #define HRT_FINE_MIN_TRI 1024u
-#define HRT_WIDE_COS 0.995f    /* half-angle 5.7 deg.  Measured (ms per step, 3 M rays; city 25 k / 100 k, room 24 k):
+#define HRT_WIDE_COS 0.995f    /* half-angle 5.7 deg.  Measured (ms per step, 1 M rays; city 25 k / 100 k, room 24 k):
                                 * 0.5 15.4 / 56.7 / 22.2, 0.95 8.4 / 31.7 / 10.9, 0.99 7.5 / 27.8 / 11.0, 0.995 7.2 / 26.4,
                                 * 0.999 7.0 / 25.0 / 11.5, every packet 10.7 / 38.2 / 16.6 */
 
