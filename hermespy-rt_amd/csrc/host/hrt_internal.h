@@ -68,6 +68,7 @@ struct hrt_problem {
     /* one device allocation holding everything */
     void *d_blob;
     const float *d_tri, *d_mesh, *d_mat, *d_rx_pos, *d_tx_pos, *d_rx_vel, *d_tx_vel;
+    const uint32_t *d_inv;      /* [T] original index -> table row (only with the fine leaves: the wide kernels) */
     hrt_kaccel kaccel;           /* device pointers of the acceleration structure */
     void *d_rxt;                 /* per-RX direction tables (device blob), or NULL */
     hrt_krxt krxt;

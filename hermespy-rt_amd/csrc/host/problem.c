@@ -499,8 +499,7 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
     if (A->fine) {
         ka->fine = (const float *)(b + offs[i_fine]);
         ka->num_fine = A->num_fine;
-        ka->inv = (const uint32_t *)(b + offs[i_inv]);
-        { const char *wc = getenv("HRT_WIDE_COS"); ka->wide_cos = (wc && *wc) ? (float)atof(wc) : HRT_WIDE_COS; }
+        p->d_inv = (const uint32_t *)(b + offs[i_inv]);
     }
     {   /* bounding box of the finite vertices (cells of the re-sort keys), and whether to re-sort */
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -1044,6 +1043,8 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.off_lb = L.off_lb;
     K.lb_stride = (uint32_t)L.lb_stride;
     K.off_wide_q = L.off_wide_q; K.off_wide_key = L.off_wide_key; K.wide_cap = (uint32_t)L.wide_cap;
+    K.wide_inv = p->d_inv;
+    { const char *wc = getenv("HRT_WIDE_COS"); K.wide_cos = (wc && *wc) ? (float)atof(wc) : HRT_WIDE_COS; }
     K.lb_chunks = (uint32_t)round_up(L.cap / HRT_BLOCK + 1, 64);
     K.fuse = fuse_mode(p);
     if (p->sort_rays) {

@@ -1180,6 +1180,7 @@ struct WideQ {
     unsigned long long *q = nullptr;
     unsigned long long *keys = nullptr;
     uint32_t cap = 0u;
+    float cos_min = 0.f;                  // packets with a wider cone are queued
     unsigned long long entry = 0ull;
 };
 
@@ -1260,7 +1261,7 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
 #ifdef HRT_UNIT_CLOCKS
     if (lane == 0) { ws[15] = P0.usable ? 1u : 0u; ws[14] = 0u; ws[13] = (uint32_t)(fmaxf(P0.cosa, 0.f) * 255.f); ws[12] = 0u; }
 #endif
-    const bool wide = !P0.usable || !(P0.cosa >= A.wide_cos);
+    const bool wide = !P0.usable || !(P0.cosa >= wq.cos_min);
     if (wide) {
         uint32_t slot = 0xffffffffu;
         if (wq.cnt != nullptr) {
@@ -1806,6 +1807,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
                 wq.q = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_q);
                 wq.keys = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_key);
                 wq.cap = P.wide_cap;
+                wq.cos_min = P.wide_cos;
                 wq.entry = ((unsigned long long)chunk << 32) | ((unsigned long long)k << 2) | (tid >> 6);
             }
         }
@@ -1880,7 +1882,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
             __syncthreads();
             if (tid == 0) {
                 const uint32_t c = l_wcnt[0] + l_wcnt[1] + l_wcnt[2] + l_wcnt[3];
-                reinterpret_cast<uint4 *>(P.ws + P.off_chunk_cnt)[chunk] = make_uint4(c, 0u, 0u, 0u);
+                reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] = c;
                 // ... and the sum over every HRT_SUPER_CHUNKS chunks ("super-chunk"): two short sums in the
                 // shade kernel then replace a scan pass over all chunks
                 atomicAdd(reinterpret_cast<uint32_t *>(P.ws + P.off_super_cnt) +
@@ -2116,7 +2118,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_wide_finish_kernel(const hrt_kp
         const unsigned long long key = keys[(uint64_t)e * 64u + lane];
         Hit h = {HRT_NO_HIT, 1e9f};
         if (key != ~0ull) {
-            h.tri = P.acc.inv[(uint32_t)key];
+            h.tri = P.wide_inv[(uint32_t)key];
             h.t = __uint_as_float((uint32_t)(key >> 32));
         }
         if (valid) {   // (the trace kernel's result words)
@@ -2403,8 +2405,13 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                 const uint32_t n_sup =
                     (chunk == 0) ? ((n_in + HRT_BLOCK - 1) / HRT_BLOCK + HRT_SUPER_CHUNKS - 1u) >> HRT_SUPER_SHIFT : sup;
                 for (uint32_t q = tid; q < n_sup; q += HRT_BLOCK) part += scnt[q];
-                const uint32_t cw = ((sup << HRT_SUPER_SHIFT) << 2) + tid;   // one word per wave of a chunk
-                if (chunk != 0 && tid < 4u * HRT_SUPER_CHUNKS && (cw >> 2) < chunk) part += ccnt[cw];
+                if (P.cnt_per_wave) {   // (the fine walk: one word per wave of a chunk)
+                    const uint32_t cw = ((sup << HRT_SUPER_SHIFT) << 2) + tid;
+                    if (chunk != 0 && tid < 4u * HRT_SUPER_CHUNKS && (cw >> 2) < chunk) part += ccnt[cw];
+                } else {
+                    const uint32_t c = (sup << HRT_SUPER_SHIFT) + tid;
+                    if (chunk != 0 && tid < HRT_SUPER_CHUNKS && c < chunk) part += ccnt[c];
+                }
             }
             part = wave_sum_u32(part);
             const unsigned long long m = __ballot(hit);
@@ -3606,9 +3613,25 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
     return (v && *v) ? (uint64_t)atoll(v) : dflt;
 }
 
-// geometry of launch `bounce`: the trace kernel (all shadow + primary traces of the live list)
-int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
+// does this problem walk the fine leaves (tables beyond LDS with fine spheres built, no big-table trees)?
+static bool walks_fine(const hrt_kparams *P)
 {
+    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
+    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const uint64_t T = P->num_tri;
+    const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
+                               (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
+    const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
+    const bool trees = P->acc.big && (variant >= 4) && variant != 9;
+    return !in_lds && !trees && P->acc.fine != nullptr && (variant == 7 || variant == 9);
+}
+
+// geometry of launch `bounce`: the trace kernel (all shadow + primary traces of the live list)
+int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
+{
+    hrt_kparams Pc = *P_in;
+    Pc.cnt_per_wave = walks_fine(P_in) ? 1u : 0u;
+    const hrt_kparams *P = &Pc;
     // Shapes are validated by the host (hrt_trace); here only the launch geometry.
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
     const uint64_t kinds = (bounce == 0) ? 1u : (bounce < P->num_bounces ? P->num_rx + 1u : P->num_rx);
@@ -3670,8 +3693,11 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream)
 }
 
 // shading of launch `bounce`: records of bounce-1, the bounce itself, compaction step 1
-int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream)
+int hrt_hip_launch_shade(const hrt_kparams *P_in, uint32_t bounce, void *stream)
 {
+    hrt_kparams Pc = *P_in;
+    Pc.cnt_per_wave = walks_fine(P_in) ? 1u : 0u;
+    const hrt_kparams *P = &Pc;
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
     uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
     static const uint64_t max_grid = env_u64("HRT_SHADE_GRID", HRT_SHADE_GRID);

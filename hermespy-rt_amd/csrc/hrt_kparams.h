@@ -48,7 +48,8 @@ typedef struct {
     uint32_t num_leaf;
     uint32_t big;                   /* inner levels + plane tree present */
     uint32_t dbg;                   /* HRT_ACCEL_DEBUG bits (timing experiments only): 2 skip the plane tree
-                                     * (UNSOUND), 8 cut unusable packets into lane ranges (4: down to 8 lanes) */
+                                     * (UNSOUND), 8 cut unusable packets into lane ranges (4: down to 8 lanes),
+                                     * 16 the wide kernel runs every slice flat (no culling) */
     uint32_t num_levels;
     uint32_t node_count[HRT_ACCEL_MAX_LEVELS];
     const float *node[HRT_ACCEL_MAX_LEVELS];
@@ -62,8 +63,6 @@ typedef struct {
      * HRT_FINE_MIN_TRI triangles without the big-table trees; NULL otherwise */
     const float *fine;
     uint32_t num_fine;
-    const uint32_t *inv;            /* [T] index in the reference's loop order -> table row (the inverse of orig) */
-    float wide_cos;                 /* fine walk: packets whose cone is wider than this cosine go to the wide kernels */
 } hrt_kaccel;
 #define HRT_FINE_ROWS 16u
 #define HRT_FINE_MIN_TRI 1024u
@@ -158,6 +157,10 @@ typedef struct {
      * the u32 at off_counts + HRT_CNT_WIDE + 4 b (zeroed with the counts).  wide_cap 0: no queue */
     uint64_t off_wide_q, off_wide_key;
     uint32_t wide_cap;
+    float wide_cos;          /* fine walk: packets whose cone is wider than this cosine go to the wide kernels */
+    const uint32_t *wide_inv;   /* [T] index in the reference's loop order -> table row (the inverse of acc.orig) */
+    uint32_t cnt_per_wave;   /* survivor counts at off_chunk_cnt: 1 = one word per WAVE of a chunk (the fine walk, whose
+                              * waves do not wait for each other), 0 = one per chunk; set by the launch shims */
 } hrt_kparams;
 
 /* the counter block at off_counts (HRT_CNT_BYTES, zeroed at the start of every trace): counts[nb + 2] |
