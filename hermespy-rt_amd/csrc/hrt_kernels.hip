@@ -1824,7 +1824,9 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT
 #ifdef HRT_UNIT_CLOCKS
         if (lane == 0) {
             const unsigned long long dt = wall_clock64() - t_w0;
-            const unsigned int slot = atomicAdd(&g_unit_n, 1u) & ((1u << 21) - 1u);
+            // (no counter: half a million same-address atomics per step would be the measurement)
+            const unsigned int slot = (b * 600011u + unit * 4u + (tid >> 6)) & ((1u << 21) - 1u);
+            if (unit == 0u && tid == 0u) atomicMax(&g_unit_n, 1u << 21);
             g_unit[slot][0] = t_w0;
             g_unit[slot][1] = dt | ((unsigned long long)(shadow ? 2 : (first ? 0 : 1)) << 56) |
                               ((unsigned long long)(reinterpret_cast<uint32_t *>(l_wleaf)[15] & 1u) << 60) |
@@ -3877,7 +3879,12 @@ int hrt_hip_read_stats(unsigned long long *out, int reset)
             if (n > (1u << 21)) n = 1u << 21;
             if (FILE *f = fopen(uf, "wb")) { fwrite(host_unit, 16, n, f); fclose(f); }
         }
-        if (reset) { n = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_n), &n, sizeof n); }
+        if (reset) {
+            n = 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_n), &n, sizeof n);
+            void *gu = nullptr;
+            if (hipGetSymbolAddress(&gu, HIP_SYMBOL(g_unit)) == hipSuccess) (void)hipMemset(gu, 0, sizeof(unsigned long long) * 2u << 21);
+        }
     }
 #endif
 #if defined(HRT_KERNEL_STATS) || defined(HRT_PHASE_STATS)
