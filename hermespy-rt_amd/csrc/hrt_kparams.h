@@ -164,9 +164,10 @@ typedef struct {
 } hrt_kparams;
 
 /* the counter block at off_counts (HRT_CNT_BYTES, zeroed at the start of every trace): counts[nb + 2] |
- * one work-unit counter per launch (trees) | one wide-queue entry count per launch */
+ * one work-unit counter per launch (trees) | one wide-queue entry count per launch | LoS words */
 #define HRT_CNT_UNITS 256u
 #define HRT_CNT_WIDE 512u
+#define HRT_CNT_LOS 768u       /* big-table LoS pass: {max of ~distance bits, waves done} per (rx, tx) pair, up to 32 pairs */
 #define HRT_CNT_BYTES 1024u
 #define HRT_WIDE_SLICE 1024u  /* table rows of one (packet, slice) item of hrt_wide_kernel: 64 fine spheres */
 
