@@ -53,6 +53,15 @@ __global__ void fma64(double *out, double a, double b, int iters) {
         asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x6) : "v"(a), "v"(b)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x7) : "v"(a), "v"(b));
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7; }
+// packed fp32 (two IEEE operations per lane and instruction, operands in VGPR pairs)
+#define KERNEL_PK(NAME, INS) \
+__global__ void NAME(double *out, double a, double b, int iters) { \
+    double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+    for (int i = 0; i < iters; ++i) { BODY8(INS) } \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7; }
+KERNEL_PK(pkmul8, "v_pk_mul_f32 %0, %0, %1")
+KERNEL_PK(pkadd8, "v_pk_add_f32 %0, %0, %2")
+KERNEL_PK(pkfma8, "v_pk_fma_f32 %0, %0, %1, %2")
 template <typename K, typename T> void run(const char *name, K k, T *d, int iters, int blocks_per_cu, T a, T b)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -90,5 +99,8 @@ int main()
     run("rcp", rcp8, d, it, 8, 1.0001f, 0.5f);
     run("add dpp", dpp8, d, it, 8, 1.0001f, 0.5f);
     run("fma f64", fma64, (double *)d, it, 8, 1.0001, 0.5);
+    run("pk_mul", pkmul8, (double *)d, it, 8, 1.0001, 0.5);
+    run("pk_add", pkadd8, (double *)d, it, 8, 1.0001, 0.5);
+    run("pk_fma", pkfma8, (double *)d, it, 8, 1.0001, 0.5);
     return 0;
 }
