@@ -64,9 +64,11 @@ print("ACCEL_OK", len(cases))
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_WIDE_CAP="3"),
     dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_WIDE_CAP="0", HRT_SORT_RAYS="1"),
     dict(HRT_LOS_BIG_MIN_TRI="0"),                 # the big tables' sliced LoS kernel on every table
+    # fine leaves + queue on two logical devices, each running several batches through a small workspace
+    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_DEVICES="0,0", HRT_WORKSPACE_BYTES="8000000"),
 ], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order",
         "rx_tables_only", "no_tables", "tables_by_size", "fine", "fine_resort", "fine_ref_order", "fine_queue_overflow",
-        "fine_no_queue", "los_sliced"])
+        "fine_no_queue", "los_sliced", "fine_devices_batches"])
 def test_modes_are_bit_identical_to_the_oracle(env):
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
                        capture_output=True, text=True)
