@@ -13,14 +13,21 @@ from hermespy_rt_amd import lib  # noqa: E402
 from hermespy_rt_amd.device import Tracer  # noqa: E402
 from tests import scenes_gen as G  # noqa: E402
 
-nb = int(sys.argv[1])
-rays = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 p = os.path.join(tempfile.mkdtemp(), "room.hrt")
-if os.environ.get("HRT_SCALING_SCENE", "room") == "city":
+if sys.argv[1] in ("c1", "c2", "c3", "c4", "c5"):   # a bench workload instead of a generated scene
+    from hermespy_rt_amd.workloads import WORKLOADS
+    w = WORKLOADS[sys.argv[1]]
+    T = -1
+    tr = Tracer(w["scene_path"], w["rx_pos"], w["tx_pos"], w["rx_vel"], w["tx_vel"], w["f_ghz"], w["num_paths"], w["num_bounces"])
+elif os.environ.get("HRT_SCALING_SCENE", "room") == "city":
+    nb = int(sys.argv[1])
+    rays = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
     T, _ = G.city(p, nb)
     tr = Tracer(p, [[60.0, 0.0, 1.5], [0.0, -90.0, 1.5], [-150.0, 30.0, 1.5]], [[0.0, 0.0, 25.0]], [[0, 0, 0]] * 3,
                 [[0, 0, 0]], 3.5, rays, 2)
 else:
+    nb = int(sys.argv[1])
+    rays = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
     T = G.room_with_clutter(p, nb, seed=7, tilt=True, scale=max(1.0, (nb / 500.0) ** (1.0 / 3.0)))
     tr = Tracer(p, [[5, 3, 1.5], [-8, -4, 2.0], [12, 9, 8.0]], [[-10, 5, 6.0]], [[0, 0, 0]] * 3, [[0, 0, 0]], 3.5, rays, 2)
 arr = (ctypes.c_uint64 * 48)()
