@@ -214,6 +214,9 @@ def main():
     rehearse = os.environ.get("HRT_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+        # (the fused launches spin on prefix words in dispatch order: N processes time-sharing one GPU make
+        # that wait take seconds -- INTEGRATION.md "Threads and processes")
+        os.environ.setdefault("HRT_FUSE", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
