@@ -46,6 +46,16 @@ tr.trace()
 torch.cuda.synchronize()
 L.hrt_debug_kernel_stats(0, arr, 0)
 u = np.fromfile(uf, dtype=np.uint64).reshape(-1, 2)
+u2 = np.fromfile(uf + ".2", dtype=np.uint64).reshape(-1, 2) if os.path.exists(uf + ".2") else None
+if u2 is not None:   # phases of a unit around its trace (10 ns ticks), and the workgroup's start-up
+    m2 = u[:, 0] != 0
+    pre = (u2[m2, 0] & np.uint64(0xffffffff)).astype(np.int64) / 100.0
+    post = (u2[m2, 0] >> np.uint64(32)).astype(np.int64) / 100.0
+    st = u2[m2, 1].astype(np.int64) / 100.0
+    trc = (u[m2, 1] & np.uint64((1 << 24) - 1)).astype(np.int64) / 100.0
+    print(f"unit phases (us, mean / median): unit start -> trace start {pre.mean():.2f} / {np.median(pre):.2f}, trace {trc.mean():.2f} / "
+          f"{np.median(trc):.2f}, trace end -> unit end {post.mean():.2f} / {np.median(post):.2f}; kernel entry -> first unit "
+          f"{st[st > 0].mean():.2f} / {np.median(st[st > 0]):.2f} (n = {(st > 0).sum()})")
 u = u[u[:, 0] != 0]   # (slots are hashed, not counted: unused ones are zero)
 t0 = u[:, 0].astype(np.int64)
 dt = (u[:, 1] & np.uint64((1 << 24) - 1)).astype(np.int64)
