@@ -1044,7 +1044,10 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.lb_stride = (uint32_t)L.lb_stride;
     K.off_wide_q = L.off_wide_q; K.off_wide_key = L.off_wide_key; K.wide_cap = (uint32_t)L.wide_cap;
     K.wide_inv = p->d_inv;
-    { const char *wc = getenv("HRT_WIDE_COS"); K.wide_cos = (wc && *wc) ? (float)atof(wc) : HRT_WIDE_COS; }
+    {
+        const char *wc = getenv("HRT_WIDE_COS");
+        K.wide_cos = (wc && *wc) ? (float)atof(wc) : (p->num_tri >= HRT_WIDE_COS_BIG_TRI ? HRT_WIDE_COS_BIG : HRT_WIDE_COS);
+    }
     K.lb_chunks = (uint32_t)round_up(L.cap / HRT_BLOCK + 1, 64);
     K.fuse = fuse_mode(p);
     if (p->sort_rays) {

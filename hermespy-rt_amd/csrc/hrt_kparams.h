@@ -69,6 +69,10 @@ typedef struct {
 #define HRT_WIDE_COS 0.995f    /* half-angle 5.7 deg.  Measured (ms per step, 1 M rays; city 25 k / 100 k, room 24 k):
                                 * 0.5 15.4 / 56.7 / 22.2, 0.95 8.4 / 31.7 / 10.9, 0.99 7.5 / 27.8 / 11.0, 0.995 7.2 / 26.4,
                                 * 0.999 7.0 / 25.0 / 11.5, every packet 10.7 / 38.2 / 16.6 */
+#define HRT_WIDE_COS_BIG 0.998f      /* ... on tables of HRT_WIDE_COS_BIG_TRI triangles or more (final code, city 25 k / 100 k / 199 k, room
+                                       * 24 k: 0.995 6.45 / 22.1 / 32.1 / 11.2, 0.998 6.02 / 21.1 / 28.7 / 10.9, 0.999 5.98 / 20.4 / 29.0 / 11.3; the
+                                       * smaller tables lose 2 % at 0.998) */
+#define HRT_WIDE_COS_BIG_TRI 16384u
 
 /* ---- per-RX direction tables for the shadow rays (host: problem.c; kernels: closest_hit_packet) ----
  * All shadow rays of a trace kind converge on one RX, so which triangles can possibly be met is a
