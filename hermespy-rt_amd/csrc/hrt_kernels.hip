@@ -1939,7 +1939,7 @@ __device__ __forceinline__ void wide_entry_ray(const hrt_kparams &P, const uint3
     }
 }
 
-constexpr uint32_t kWideGrid = 2048u;   // workgroups of hrt_wide_kernel (4 waves each)
+constexpr uint32_t kWideGrid = 8192u;   // workgroups of hrt_wide_kernel, 4 waves each (HRT_WIDE_GRID; city 100 k: 1 280 20.9 ms, 2 048 20.4, 4 096 19.7, 8 192 19.2, 16 384 19.1)
 static_assert(HRT_WIDE_SLICE == 64u * HRT_FINE_ROWS, "a slice is one round of fine spheres");
 
 // A slice of a USABLE packet (one that was queued because its cone is wide: its walk would take
@@ -3756,7 +3756,8 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     if (fine) {
         launch_trace_t<false, 9>(P, bounce, nb, lds, st, &err);
         if (err == hipSuccess && P->wide_cap != 0u) {   // the packets the walk queued as too wide to cull
-            hipLaunchKernelGGL(hrt_wide_kernel, dim3(kWideGrid), dim3(HRT_BLOCK), 0, st, *P, bounce);
+            static const uint64_t wide_grid = env_u64("HRT_WIDE_GRID", kWideGrid);
+            hipLaunchKernelGGL(hrt_wide_kernel, dim3((uint32_t)wide_grid), dim3(HRT_BLOCK), 0, st, *P, bounce);
             hipLaunchKernelGGL(hrt_wide_finish_kernel, dim3(256), dim3(HRT_BLOCK), 0, st, *P, bounce);
         }
     } else if (in_lds) {

@@ -72,7 +72,7 @@ typedef struct {
 #define HRT_WIDE_COS_BIG 0.998f      /* ... on tables of HRT_WIDE_COS_BIG_TRI triangles or more (final code, city 25 k / 100 k / 199 k, room
                                        * 24 k: 0.995 6.45 / 22.1 / 32.1 / 11.2, 0.998 6.02 / 21.1 / 28.7 / 10.9, 0.999 5.98 / 20.4 / 29.0 / 11.3; the
                                        * smaller tables lose 2 % at 0.998) */
-#define HRT_WIDE_COS_BIG_TRI 16384u
+#define HRT_WIDE_COS_BIG_TRI 4096u   /* (with 8 192 workgroups in the wide kernel: 6 012 triangles 3.73 -> 3.67 ms at 0.998, 1 212: 1.61 -> 1.63) */
 
 /* ---- per-RX direction tables for the shadow rays (host: problem.c; kernels: closest_hit_packet) ----
  * All shadow rays of a trace kind converge on one RX, so which triangles can possibly be met is a
