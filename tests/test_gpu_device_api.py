@@ -124,3 +124,35 @@ def test_rays_per_shard_limit():
     halves = _lib.Shard(limit + 4096, 1, 2, 0, 1)
     assert L.hrt_layout_query(tr.problem, C.byref(halves), C.byref(lay)) == 0
     tr.close()
+
+
+def test_layout_has_the_wide_packet_queue_only_beyond_1024_triangles(tmp_path):
+    """hrt_layout (include/hrt_device.h): tables with fine leaves (more than 1 024 triangles) carry the queue
+    of wide packets -- entries and 64 keys each, between the survivor counts (four words per chunk) and the
+    trace results --; small tables carry no queue."""
+    import ctypes as C
+    from hermespy_rt_amd import lib as _lib
+    from hermespy_rt_amd.device import Tracer
+    from . import scenes_gen as G
+    L = _lib.load()
+    p = str(tmp_path / "room.hrt")
+    T = G.room_with_clutter(p, 100, seed=3, tilt=True)
+    assert T > 1024
+    big = Tracer(p, [[5, 3, 1.5], [-8, -4, 2.0]], [[-10, 5, 6.0]], [[0, 0, 0]] * 2, [[0, 0, 0]], 3.5, 100000, 2)
+    c = K.small(K.C3, 100000)
+    small = Tracer(c["scene_path"], c["rx_pos"], c["tx_pos"], c["rx_vel"], c["tx_vel"], c["f_ghz"], c["num_paths"],
+                   c["num_bounces"])
+    lay = _lib.Layout()
+    sh = _lib.Shard(100000, 0, 1, 0, 2)
+    assert L.hrt_layout_query(big.problem, C.byref(sh), C.byref(lay)) == 0
+    traces = (lay.cap // 64) * (2 + 1)
+    assert lay.wide_cap == max(1024, traces // 2)
+    assert lay.off_chunk_cnt < lay.off_wide_q < lay.off_wide_key < lay.off_res < lay.total_bytes
+    assert lay.off_wide_q - lay.off_chunk_cnt >= (lay.cap // 256) * 16
+    assert lay.off_wide_q + lay.wide_cap * 8 <= lay.off_wide_key
+    assert lay.off_wide_key + lay.wide_cap * 64 * 8 <= lay.off_res
+    sh = _lib.Shard(100000, 0, 1, 0, 4)
+    assert L.hrt_layout_query(small.problem, C.byref(sh), C.byref(lay)) == 0
+    assert lay.wide_cap == 0 and lay.off_wide_q == 0 and lay.off_wide_key == 0
+    big.close()
+    small.close()
