@@ -1666,8 +1666,12 @@ __device__ __forceinline__ F3 shadow_dir(F3 o, F3 rx, float &d2rx)
 #ifndef HRT_TRACE_WAVES_V2
 #define HRT_TRACE_WAVES_V2 7   /* the small-table packet kernel: at most 72 VGPRs (measured C3: 1.704 ms at 7, 1.706 at 8 with 28 B of scratch, 1.743 at 6, 1.757 unconstrained) */
 #endif
+#ifndef HRT_TRACE_WAVES_FINE
+#define HRT_TRACE_WAVES_FINE 8   /* the fine walk is bound by dependent loads: 8 waves per SIMD (64 registers, some scratch) beat
+                                  * the 5 it takes unconstrained (95 registers): city 100 k 19.4 -> 18.4 ms, room 24 k 10.0 -> 9.4 */
+#endif
 template <bool TRI_IN_LDS, int VARIANT>
-__global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : HRT_TRACE_WAVES_PER_SIMD)) void hrt_trace_kernel(
+__global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VARIANT == 9 ? HRT_TRACE_WAVES_FINE : HRT_TRACE_WAVES_PER_SIMD))) void hrt_trace_kernel(
     const hrt_kparams P, const uint32_t b)
 {
     extern __shared__ float4 lds[];
@@ -1949,7 +1953,10 @@ static_assert(HRT_WIDE_SLICE == 64u * HRT_FINE_ROWS, "a slice is one round of fi
 // (|d.n| > Gamma_i for every ray) is rejected by the lemma's first term (DESIGN_ACCEL.md B.4), any other
 // is judged by its own ball (p1, l) exactly as the plane tree's leaves judge theirs, and what is not
 // cleared is packet-tested and, if it survives, staged-tested.
-__global__ __launch_bounds__(HRT_BLOCK) void hrt_wide_kernel(const hrt_kparams P, const uint32_t b)
+#ifndef HRT_WIDE_WAVES
+#define HRT_WIDE_WAVES 6   /* (5 unconstrained at 89 registers; room of 24 012: 9.4 -> 9.05 ms at 6, 9.3 at 8) */
+#endif
+__global__ __launch_bounds__(HRT_BLOCK, HRT_WIDE_WAVES) void hrt_wide_kernel(const hrt_kparams P, const uint32_t b)
 {
     __shared__ float4 l_rows[HRT_BLOCK / 64u][kCandBuf * 4u];
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
