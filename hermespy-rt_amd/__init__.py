@@ -11,7 +11,8 @@ hermespy-rt_amd/lib/.
 import os
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(PACKAGE_DIR, "lib")
+# HRT_LIB_DIR: an instrumented build of the same sources in another directory (profiles/ scripts only)
+LIB_DIR = os.environ.get("HRT_LIB_DIR") or os.path.join(PACKAGE_DIR, "lib")
 REPO_DIR = os.path.dirname(PACKAGE_DIR)
 SCENES_DIR = os.path.join(REPO_DIR, "scenes")
 

@@ -73,6 +73,8 @@ struct hrt_problem {
     void *d_rxt;                 /* per-RX direction tables (device blob), or NULL */
     hrt_krxt krxt;
     uint64_t rxt_entries;        /* total list entries over all (rx, cell) */
+    void *d_patch;               /* patch tables (device blob), or NULL */
+    hrt_kpatch kpatch;
     int sort_rays;               /* re-sort the live list between bounces (hrt_ksort) */
     float scene_lo[3], scene_hi[3];   /* bounding box of the (finite) vertices */
 };

@@ -71,6 +71,7 @@ void hrt_problem_destroy(hrt_problem *p)
         hrt_hip_set_device(p->device);
         hrt_hip_free(p->d_blob);
         if (p->d_rxt) hrt_hip_free(p->d_rxt);
+        if (p->d_patch) hrt_hip_free(p->d_patch);
     }
     free(p->h_tri); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
     hrt_accel_free(&p->accel);
@@ -270,6 +271,128 @@ out:
     if (d_tmp) hrt_hip_free(d_tmp);
     free(ro_bin); free(apex); free(masks); free(off); free(idx);
     if (rc && p->d_rxt) { hrt_hip_free(p->d_rxt); p->d_rxt = NULL; p->krxt.cell_mask = NULL; }
+    return rc;
+}
+
+/* ---- patch tables (hrt_kpatch, hrt_kparams.h): the grid of every triangle, the list patch -> triangle,
+ * and the device pass that fills the candidate masks.  Tables of 65 .. HRT_PATCH_MAX_TRI triangles. ----
+ * Patch edge: HRT_PATCH_SIZE metres (default 0.5: C3 4.5 candidates per shadow ray against 7.4 at 1 m and
+ * 17.7 at 2 m, profiles/study/), enlarged until all tables fit HRT_PATCH_MAX_BYTES (default 1 GiB). */
+static int patch_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
+{
+    const uint32_t T = p->num_tri, n_rx = p->num_rx, n_tx = p->num_tx;
+    { const char *v = getenv("HRT_NO_PATCH"); if (v && *v && *v != '0') return HRT_OK; }
+    if (T <= 64u || T > HRT_PATCH_MAX_TRI || n_rx + n_tx > 4096u) return HRT_OK;
+    double size = 0.5, max_bytes = 1024.0 * 1024.0 * 1024.0;
+    { const char *v = getenv("HRT_PATCH_SIZE"); if (v && *v && atof(v) > 0.0) size = atof(v); }
+    { const char *v = getenv("HRT_PATCH_MAX_BYTES"); if (v && *v && atof(v) > 0.0) max_bytes = atof(v); }
+    if (max_bytes > 3.5e9) max_bytes = 3.5e9;   /* the kernels address the masks with 32-bit byte offsets */
+    /* extent of everything a ray origin or an apex can be */
+    double ext1 = 0.0, cmax = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        ext1 += (double)p->scene_hi[k] - (double)p->scene_lo[k];
+        cmax += fmax(fabs((double)p->scene_hi[k]), fabs((double)p->scene_lo[k]));
+    }
+    if (!isfinite(ext1) || !isfinite(cmax)) return HRT_OK;
+    const double u = 5.9604644775390625e-08;   /* 2^-24 */
+    const double Smax = ext1 + 1.0;            /* >= |o - v1| for any origin within hmax of the scene's box */
+    const float hmax = (float)(4e-4 + 4e-6 * cmax);
+    const uint32_t n_apex = n_rx + n_tx;
+    float *pdef = (float *)calloc((size_t)T * 8, sizeof(float));
+    uint32_t *nuv = (uint32_t *)calloc((size_t)T * 2, sizeof(uint32_t));
+    uint32_t *ptri = NULL;
+    float *apex = (float *)malloc((size_t)n_apex * 3 * sizeof(float));
+    void *d_tmp = NULL;
+    int rc = HRT_OK, e;
+    uint64_t npatch = 0;
+    if (!pdef || !nuv || !apex) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
+    for (int pass = 0; pass < 32; ++pass) {
+        npatch = 0;
+        for (uint32_t j = 0; j < T; ++j) {
+            const float *r = p->h_tri + (size_t)j * HRT_TRI_FLOATS;
+            const double e1[3] = {r[3], r[4], r[5]}, e2[3] = {r[6], r[7], r[8]};
+            const double a11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+            const double a22 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+            const double a12 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+            const double det = a11 * a22 - a12 * a12;
+            nuv[2 * j] = nuv[2 * j + 1] = 0u;
+            if (!(det > 1e-30) || !isfinite(det) || !isfinite(r[9] + r[10] + r[11])) continue;   /* degenerate: not served */
+            double nu = ceil(sqrt(a11) / size), nv = ceil(sqrt(a22) / size);
+            if (nu < 1) nu = 1;
+            if (nv < 1) nv = 1;
+            if (nu > 2048) nu = 2048;
+            if (nv > 2048) nv = 2048;
+            double g1[3], g2[3], l1 = 0, l2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                g1[k] = (a22 * e1[k] - a12 * e2[k]) / det * nu;
+                g2[k] = (a11 * e2[k] - a12 * e1[k]) / det * nv;
+                l1 += g1[k] * g1[k];
+                l2 += g2[k] * g2[k];
+            }
+            /* rounding of the kernel's cell coordinates (s = o - v1, three fused terms): must stay below
+             * 1/64 of a cell -- with the clamp of HRT_PATCH_ACCEPT an origin is then never further than
+             * HRT_PATCH_MARGIN outside its cell (needle triangles fail this and are not served) */
+            const double v1n = fabs((double)r[0]) + fabs((double)r[1]) + fabs((double)r[2]);
+            if (!(16.0 * u * (Smax + v1n) * sqrt(l1 > l2 ? l1 : l2) <= 1.0 / 64.0)) continue;
+            nuv[2 * j] = (uint32_t)nu;
+            nuv[2 * j + 1] = (uint32_t)nv;
+            float *q = pdef + (size_t)j * 8;
+            const uint32_t base = (uint32_t)npatch, bits = (uint32_t)nu | ((uint32_t)nv << 16);
+            q[0] = (float)g1[0]; q[1] = (float)g1[1]; q[2] = (float)g1[2]; memcpy(&q[3], &base, 4);
+            q[4] = (float)g2[0]; q[5] = (float)g2[1]; q[6] = (float)g2[2]; memcpy(&q[7], &bits, 4);
+            npatch += (uint64_t)(nu * nv);
+        }
+        if (npatch == 0) goto out;
+        const double bytes = (double)npatch * n_apex * HRT_PATCH_WORDS * 8.0;
+        if (bytes <= max_bytes && npatch < 0x7fffffffull) break;
+        size *= fmax(1.05, sqrt(bytes / max_bytes) * 1.02);
+        if (pass == 31) goto out;   /* (cannot happen: the size grows geometrically) */
+    }
+    for (uint32_t j = 0; j < T; ++j)   /* unserved triangles: nu = nv = 0 in the table */
+        if (nuv[2 * j] == 0u) { uint32_t z = 0; float *q = pdef + (size_t)j * 8; memcpy(&q[3], &z, 4); memcpy(&q[7], &z, 4); }
+    ptri = (uint32_t *)malloc((size_t)npatch * 4);
+    if (!ptri) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
+    {
+        uint64_t k = 0;
+        for (uint32_t j = 0; j < T; ++j)
+            for (uint64_t c = 0; c < (uint64_t)nuv[2 * j] * nuv[2 * j + 1]; ++c) ptri[k++] = j;
+    }
+    for (uint32_t a = 0; a < n_apex; ++a) {
+        const Vec3 v = a < n_rx ? rx_pos[a] : tx_pos[a - n_rx];
+        if (!isfinite(v.x) || !isfinite(v.y) || !isfinite(v.z)) goto out;   /* an apex at infinity: no tables */
+        apex[3 * a] = v.x; apex[3 * a + 1] = v.y; apex[3 * a + 2] = v.z;
+        cmax = fmax(cmax, fabs((double)v.x) + fabs((double)v.y) + fabs((double)v.z));
+    }
+    {
+        /* a shadow ray built as normalise(rx - o) passes within 4 u L of the RX (packet_bounds): L <= apex
+         * distance from anywhere in the box; an image-apex lane is CHECKED against ro_img by the kernel */
+        const float ro_rx = (float)(8.0 * u * (2.0 * cmax + ext1) * 1.001 + 2e-7);
+        const float ro_img = (float)(1e-3 + 1e-5 * (cmax + ext1));
+        /* a served lane's COMPUTED plane distance is <= hmax; the true one then <= hball */
+        const float hball = (float)((double)hmax * 1.01 + 16.0 * u * (Smax + cmax));
+        const uint64_t b_pdef = round_up((uint64_t)T * 32, 256), b_mask = npatch * n_apex * HRT_PATCH_WORDS * 8;
+        const uint64_t b_ptri = round_up(npatch * 4, 256), b_apex = round_up((uint64_t)n_apex * 12, 256);
+        if ((e = hrt_hip_malloc(&p->d_patch, b_pdef + b_mask))) { p->d_patch = NULL; rc = hrt_fail_hip(e, "hipMalloc(patch tables)"); goto out; }
+        if ((e = hrt_hip_malloc(&d_tmp, b_ptri + b_apex))) { rc = hrt_fail_hip(e, "hipMalloc(patch build)"); goto out; }
+        uint8_t *q = (uint8_t *)p->d_patch;
+        if ((e = hrt_hip_h2d(q, pdef, (uint64_t)T * 32)) || (e = hrt_hip_h2d(d_tmp, ptri, npatch * 4)) ||
+            (e = hrt_hip_h2d((uint8_t *)d_tmp + b_ptri, apex, (uint64_t)n_apex * 12))) { rc = hrt_fail_hip(e, "hipMemcpy(patch build)"); goto out; }
+        if ((e = hrt_hip_patch_build(p->d_tri, T, (const float *)q, (const uint32_t *)d_tmp, (uint32_t)npatch,
+                                     (const float *)((uint8_t *)d_tmp + b_ptri), n_rx, n_tx, hball, ro_rx, ro_img,
+                                     (unsigned long long *)(q + b_pdef), NULL))) { rc = hrt_fail_hip(e, "hrt_patch_build_kernel"); goto out; }
+        if ((e = hrt_hip_stream_sync(NULL))) { rc = hrt_fail_hip(e, "hipStreamSynchronize"); goto out; }
+        p->kpatch.mask = (const unsigned long long *)(q + b_pdef);
+        p->kpatch.pdef = (const float *)q;
+        p->kpatch.num_patch = (uint32_t)npatch;
+        p->kpatch.num_img = n_tx;
+        p->kpatch.hmax = hmax;
+        p->kpatch.ro_rx = ro_rx;
+        p->kpatch.ro_img = ro_img;
+    }
+out:
+    if (d_tmp) hrt_hip_free(d_tmp);
+    free(pdef); free(nuv); free(ptri); free(apex);
+    if (rc && p->d_patch) { hrt_hip_free(p->d_patch); p->d_patch = NULL; memset(&p->kpatch, 0, sizeof p->kpatch); }
     return rc;
 }
 
@@ -531,7 +654,8 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         uint64_t min_rays = p->num_tri <= 64u ? 1ull << 18 : 1ull << 26;
         { const char *mv = getenv("HRT_RXT_MIN_RAYS"); if (mv && *mv) min_rays = strtoull(mv, NULL, 10); }
         if (rays_hint >= min_rays) {
-            const int rcx = rxt_build(p, rx_pos, tx_pos);
+            int rcx = rxt_build(p, rx_pos, tx_pos);
+            if (!rcx) rcx = patch_build(p, rx_pos, tx_pos);
             if (rcx) { hrt_problem_destroy(p); return rcx; }
         }
     }
@@ -1023,6 +1147,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.num_tri = p->num_tri; K.num_mesh = p->num_mesh;
     K.acc = p->kaccel;
     K.rxt = p->krxt;
+    K.patch = p->kpatch;
     K.rx_pos = p->d_rx_pos; K.tx_pos = p->d_tx_pos; K.rx_vel = p->d_rx_vel; K.tx_vel = p->d_tx_vel;
     K.num_rx = p->num_rx; K.num_tx = p->num_tx;
     K.fsl_mult = p->fsl_mult; K.dop_mult = p->dop_mult;

@@ -708,6 +708,120 @@ __device__ __forceinline__ Hit closest_hit_masked(TriPtr tri, const uint32_t *__
     return {who, best};
 }
 
+using Rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Rsrc make_rsrc(const uint8_t *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 0xffffffff, 0x00020000);
+}
+
+// bitwise OR of eight 32-bit words over the wave (eight interleaved in-place DPP chains: the chains fill
+// each other's read-after-write wait states), wave-uniform results
+__device__ __forceinline__ void wave_or256(uint32_t (&w)[8])
+{
+#define HRT_OR8(CTRL)                                                   \
+        "v_or_b32_dpp %0, %0, %0 " CTRL "\n" "v_or_b32_dpp %1, %1, %1 " CTRL "\n"  \
+        "v_or_b32_dpp %2, %2, %2 " CTRL "\n" "v_or_b32_dpp %3, %3, %3 " CTRL "\n"  \
+        "v_or_b32_dpp %4, %4, %4 " CTRL "\n" "v_or_b32_dpp %5, %5, %5 " CTRL "\n"  \
+        "v_or_b32_dpp %6, %6, %6 " CTRL "\n" "v_or_b32_dpp %7, %7, %7 " CTRL "\n"
+    asm volatile(
+        "s_nop 4\n"
+        HRT_OR8("row_shr:1 row_mask:0xf bank_mask:0xf")
+        HRT_OR8("row_shr:2 row_mask:0xf bank_mask:0xf")
+        HRT_OR8("row_shr:4 row_mask:0xf bank_mask:0xf")
+        HRT_OR8("row_shr:8 row_mask:0xf bank_mask:0xf")
+        HRT_OR8("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        HRT_OR8("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1\n"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+#undef HRT_OR8
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = (uint32_t)__builtin_amdgcn_readlane((int)w[k], 63);
+}
+
+// image of the point t in the plane of the triangle (v1 = q0.xyz, unit normal n = q2.yzw) -- the kernel
+// that builds the patch tables and the lanes that look them up share this sequence bit for bit
+__device__ __forceinline__ F3 image_of(F3 t, float4 q0, float4 q2)
+{
+    const F3 n = {q2.y, q2.z, q2.w};
+    const float dn = fdot3(sub3(t, {q0.x, q0.y, q0.z}), n);
+    return {__builtin_fmaf(-2.f * dn, n.x, t.x), __builtin_fmaf(-2.f * dn, n.y, t.y), __builtin_fmaf(-2.f * dn, n.z, t.z)};
+}
+
+// Patch tables (hrt_kpatch, hrt_kparams.h): every ray of a launch b >= 1 starts on the triangle it just
+// hit (row `htri`).  The lane finds the cell of that triangle's grid its origin lies in -- and is SERVED
+// only if the origin provably lies in the cell's ball: within hmax of the plane, at most HRT_PATCH_ACCEPT
+// of a cell outside the grid (whatever history put it there: the test is on the origin itself) -- and for
+// an image apex only if its line passes the apex ball, leaving it.  A served lane contributes the mask of
+// (apex, patch), any other lane of the list the whole table; the wave walks the union through the staged
+// test.  ALL lanes must call (uniform control flow).  apex_k: k (shadow rays to RX k) or num_rx + tx.
+template <typename TriPtr>
+__device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__restrict__ orig, const hrt_kpatch &X,
+                                                 uint32_t apex_k, const bool image, F3 apex, uint32_t num_tri,
+                                                 uint32_t htri, F3 o, F3 d, bool valid, uint32_t lane,
+                                                 [[maybe_unused]] int kind)
+{
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
+    const unsigned long long inval = HRT_BALLOT(!valid);
+    if (inval == ~0ull) return {who, best};
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 0u;
+    if (valid) {
+        bool served = false;
+        uint32_t off = 0u;
+        if (htri < num_tri) {
+            const float4 q0 = tri[HRT_ROW * htri], q2 = tri[HRT_ROW * htri + 2];
+            const float4 p0 = reinterpret_cast<const float4 *>(X.pdef)[2u * htri];
+            const float4 p1 = reinterpret_cast<const float4 *>(X.pdef)[2u * htri + 1u];
+            const F3 sv = sub3(o, {q0.x, q0.y, q0.z});
+            const float fu = fdot3(sv, {p0.x, p0.y, p0.z}), fv = fdot3(sv, {p1.x, p1.y, p1.z});
+            const float hh = fdot3(sv, {q2.y, q2.z, q2.w});
+            const uint32_t bits = __float_as_uint(p1.w), nu = bits & 0xffffu, nv = bits >> 16;
+            // (comparisons written so that a NaN is not served)
+            served = (nu != 0u) & (fabsf(hh) <= X.hmax) & (fu >= -HRT_PATCH_ACCEPT) & (fv >= -HRT_PATCH_ACCEPT) &
+                     (fu <= (float)nu + HRT_PATCH_ACCEPT) & (fv <= (float)nv + HRT_PATCH_ACCEPT);
+            if (image) {
+                // the apex of this lane: the image of its TX in ITS triangle's plane; the line must pass
+                // within the radius the tables were built for, leaving the apex (|d| = 1 within 1e-6)
+                const F3 im = image_of(apex, q0, q2);
+                const F3 wv = sub3(o, im);
+                const F3 cx = fcross3(wv, d);
+                served &= (fdot3(cx, cx) <= 0.98f * X.ro_img * X.ro_img) && (fdot3(wv, d) > 0.f);
+            }
+            const uint32_t iu = min((uint32_t)max((int)floorf(fu), 0), nu - 1u);
+            const uint32_t iv = min((uint32_t)max((int)floorf(fv), 0), nv - 1u);
+            off = ((apex_k * X.num_patch + __float_as_uint(p0.w)) + iv * nu + iu) * (HRT_PATCH_WORDS * 8u);
+        }
+        if (served) {
+            const Rsrc mr = make_rsrc(reinterpret_cast<const uint8_t *>(X.mask));
+            const auto a = __builtin_amdgcn_raw_buffer_load_b128(mr, (int)off, 0, 0);
+            const auto b = __builtin_amdgcn_raw_buffer_load_b128(mr, (int)(off + 16u), 0, 0);
+            w[0] = (uint32_t)a[0]; w[1] = (uint32_t)a[1]; w[2] = (uint32_t)a[2]; w[3] = (uint32_t)a[3];
+            w[4] = (uint32_t)b[0]; w[5] = (uint32_t)b[1]; w[6] = (uint32_t)b[2]; w[7] = (uint32_t)b[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                w[k] = num_tri >= 32u * (uint32_t)(k + 1) ? ~0u : (num_tri > 32u * (uint32_t)k ? (1u << (num_tri - 32u * (uint32_t)k)) - 1u : 0u);
+        }
+        HRT_STAT(kind, 6, served ? 1 : 0);
+    }
+    wave_or256(w);
+    HRT_STAT(kind, 0, 1);
+    HRT_STAT(kind, 1, 1);
+#pragma unroll
+    for (uint32_t r = 0; r < HRT_PATCH_WORDS; ++r) {
+        unsigned long long m = ((unsigned long long)w[2u * r + 1u] << 32) | (unsigned long long)w[2u * r];
+        HRT_STAT(kind, 2, __popcll(m));
+        while (m) {   // any order: ties go by (distance, original index)
+            const uint32_t j = r * 64u + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            HRT_STAGED_BODY(j)
+        }
+    }
+    return {who, best};
+}
+
 template <bool MULTI, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__restrict__ orig,
                                                   const hrt_krxt &X, uint32_t rxk,
@@ -1538,11 +1652,7 @@ __device__ __forceinline__ float acos_f_ool(float x) { return hrt_acosf(x); }
 // The host guarantees HRT_HIT_FIELDS * cap * 4 < 2^32 (hrt_layout_query), so every scalar offset
 // fits; the descriptors' range is the whole 32-bit offset space (bounds are the host's business:
 // hrt_trace checks the workspace size).
-using Rsrc = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ Rsrc make_rsrc(const uint8_t *base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 0xffffffff, 0x00020000);
-}
+// (Rsrc / make_rsrc: defined above, in front of closest_hit_patch)
 __device__ __forceinline__ float ldf(Rsrc r, uint32_t field_off, uint32_t byte_off)
 {
     return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)field_off, 0));
@@ -1768,7 +1878,10 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         const bool valid = i < n_in;
         const bool shadow = k < P.num_rx;
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
-        uint32_t tx_lane = 0u;
+        uint32_t tx_lane = 0u, htri = 0u;
+        // (patch tables: shadow rays, and the bounce rays of launch 1 -- first-order images of the TXs)
+        const bool patched = VARIANT == 2 && P.patch.mask != nullptr && !first &&
+                             (shadow || (b == 1u && P.patch.num_img != 0u));
         if (valid) {
             if (first) {
                 uint32_t ray;
@@ -1780,6 +1893,10 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
                 if (!shadow)
                     d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4),
                          ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
+                if (patched) {
+                    htri = ldu(hit_blk(P, pb), H_TRI * cap4, i4);
+                    if (!shadow && P.num_tx != 1u) tx_lane = min(ldu(hit_blk(P, pb), H_RAY * cap4, i4) / P.num_local, P.num_tx - 1u);
+                }
             }
         }
         F3 apex = {0.f, 0.f, 0.f};
@@ -1803,7 +1920,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         const bool masked = VARIANT == 2 && P.rxt.cell_mask != nullptr && (shadow || first);
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
         if constexpr (VARIANT >= 2 && VARIANT != 6)
-            if (!masked) ball = origin_ball(o, valid);
+            if (!masked && !patched) ball = origin_ball(o, valid);
         WideQ wq;
         if constexpr (VARIANT == 9) {
             if (P.wide_cap != 0u) {
@@ -1821,7 +1938,19 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
 #ifdef HRT_UNIT_CLOCKS
         const unsigned long long t_w0 = wall_clock64();
 #endif
-        const Hit h = masked ? closest_hit_masked(tri, P.acc.orig, P.rxt, shadow ? k : P.num_rx + tx_lane, T, o, d, valid,
+        Hit h = {HRT_NO_HIT, 1e9f};
+        bool done = false;
+        if constexpr (VARIANT == 2) {
+            if (patched) {
+                F3 pa = apex;   // shadow: the RX; image: the lane's own TX (mirrored per lane)
+                if (!shadow) pa = {P.tx_pos[3 * tx_lane], P.tx_pos[3 * tx_lane + 1], P.tx_pos[3 * tx_lane + 2]};
+                h = closest_hit_patch(tri, P.acc.orig, P.patch, shadow ? k : P.num_rx + tx_lane, !shadow, pa, T, htri, o, d,
+                                      valid, lane, shadow ? 2 : 1);
+                done = true;
+            }
+        }
+        if (!done)
+        h = masked ? closest_hit_masked(tri, P.acc.orig, P.rxt, shadow ? k : P.num_rx + tx_lane, T, o, d, valid,
                                                   lane, shadow ? 2 : 0)
                              : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, valid, lane,
                                                     ball, shadow, apex, l_mask, l_wleaf, shadow ? 2 : (first ? 0 : 1), wq);
@@ -3300,6 +3429,63 @@ __global__ __launch_bounds__(64) void hrt_rxt_build_kernel(const float *tri_f, u
     }
 }
 
+// Builder of the patch tables (hrt_kpatch): one thread per (patch, apex).  The patch is cell (iu, iv) of
+// the grid of triangle j, enlarged by HRT_PATCH_MARGIN of a cell on every side and by hball out of the
+// plane (the lanes are only served inside that), its packet { origins in the cell's ball, lines that meet
+// ball(apex, ro), directions within the cone the two balls span } goes through packet_culls against
+// every row of the table.  Apexes: the RXs (rays towards the apex), then per TX its image in the plane of
+// triangle j (rays leaving the apex).  A packet the test cannot serve (cone beyond 60 degrees: the apex
+// is next to the patch) keeps every triangle.  Output [apex][patch][HRT_PATCH_WORDS].
+__global__ __launch_bounds__(256) void hrt_patch_build_kernel(const float *tri_f, uint32_t num_tri, const float *pdef_f,
+                                                              const uint32_t *patch_tri, uint32_t num_patch,
+                                                              const float *apex_pos, uint32_t num_rx, float hball,
+                                                              float ro_rx, float ro_img, unsigned long long *masks)
+{
+    const float4 *tri = reinterpret_cast<const float4 *>(tri_f);
+    const float4 *pdef = reinterpret_cast<const float4 *>(pdef_f);
+    const uint32_t pid = blockIdx.x * 256u + threadIdx.x, a = blockIdx.y;
+    if (pid >= num_patch) return;
+    const uint32_t j = patch_tri[pid];
+    const float4 q0 = tri[HRT_ROW * j], q1 = tri[HRT_ROW * j + 1], q2 = tri[HRT_ROW * j + 2];
+    const float4 p0 = pdef[2u * j], p1 = pdef[2u * j + 1u];
+    const uint32_t base = __float_as_uint(p0.w), bits = __float_as_uint(p1.w), nu = bits & 0xffffu, nv = bits >> 16;
+    const uint32_t c = pid - base, iv = c / nu, iu = c - iv * nu;
+    const F3 v1 = {q0.x, q0.y, q0.z}, e1 = {q0.w, q1.x, q1.y}, e2 = {q1.z, q1.w, q2.x};
+    const float fu = ((float)iu + 0.5f) / (float)nu, fv = ((float)iv + 0.5f) / (float)nv;
+    const float hu = (0.5f + HRT_PATCH_MARGIN) / (float)nu, hv = (0.5f + HRT_PATCH_MARGIN) / (float)nv;
+    Packet P;
+    P.bc = add3(v1, add3(mul3(e1, fu), mul3(e2, fv)));
+    const F3 d1 = add3(mul3(e1, hu), mul3(e2, hv)), d2 = sub3(mul3(e1, hu), mul3(e2, hv));
+    P.br = sqrtf(fmaxf(fdot3(d1, d1), fdot3(d2, d2))) * 1.001f + hball +
+           4e-6f * ((fabsf(P.bc.x) + fabsf(P.bc.y)) + fabsf(P.bc.z));
+    const bool image = a >= num_rx;
+    const F3 ap = {apex_pos[3 * a], apex_pos[3 * a + 1], apex_pos[3 * a + 2]};
+    P.oc = image ? image_of(ap, q0, q2) : ap;
+    P.ro = image ? ro_img : ro_rx;
+    const F3 w = sub3(P.oc, P.bc);
+    const float dist = sqrtf(fdot3(w, w));
+    const float inv = (image ? -1.f : 1.f) / fmaxf(dist, 1e-30f);
+    P.ax = {w.x * inv, w.y * inv, w.z * inv};
+    // directions of the lines between the two balls: sin(half-angle) <= (br + ro) / dist
+    const float sa = (P.br + P.ro) / fmaxf(dist, 1e-30f) * 1.001f + 1e-5f;
+    P.usable = sa < 0.86f;   // (NaN: not usable)
+    P.sina = P.usable ? sa : 0.86f;
+    P.cosa = sqrtf(fmaxf(0.f, 1.f - P.sina * P.sina)) * 0.9999f - 1e-6f;
+    unsigned long long m[HRT_PATCH_WORDS];
+#pragma unroll
+    for (uint32_t r = 0; r < HRT_PATCH_WORDS; ++r) m[r] = 0ull;
+    for (uint32_t t = 0; t < num_tri; ++t) {
+        const bool cand = !P.usable || !packet_culls(P, tri[HRT_ROW * t], tri[HRT_ROW * t + 1], tri[HRT_ROW * t + 2],
+                                                    tri[HRT_ROW * t + 3], tri[HRT_ROW * t + 4]);
+#pragma unroll
+        for (uint32_t r = 0; r < HRT_PATCH_WORDS; ++r)
+            if ((t >> 6) == r && cand) m[r] |= 1ull << (t & 63u);
+    }
+    unsigned long long *out = masks + ((uint64_t)a * num_patch + pid) * HRT_PATCH_WORDS;
+#pragma unroll
+    for (uint32_t r = 0; r < HRT_PATCH_WORDS; ++r) out[r] = m[r];
+}
+
 // ===================================================================================
 // Re-sort of the survivors of bounce b (hrt_ksort): keys, then a stable radix sort of (key, index)
 // (the kernels below), then the permutation of the 15 field arrays from the scratch block into hit
@@ -3918,6 +4104,17 @@ int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_po
 {
     hipLaunchKernelGGL(hrt_rxt_build_kernel, dim3(HRT_RXT_BINS, num_rx), dim3(64), 0, (hipStream_t)stream,
                        d_tri, num_tri, d_rx_pos, d_bin_dir4, d_bin_cs2, d_ro_bin, cx, cy, cz, region_r, d_masks);
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_patch_build(const float *d_tri, uint32_t num_tri, const float *d_pdef, const uint32_t *d_patch_tri,
+                        uint32_t num_patch, const float *d_apex, uint32_t num_rx, uint32_t num_img, float hball,
+                        float ro_rx, float ro_img, unsigned long long *d_masks, void *stream)
+{
+    if (num_patch == 0 || num_rx + num_img == 0 || num_rx + num_img > 65535u) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(hrt_patch_build_kernel, dim3((num_patch + 255u) / 256u, num_rx + num_img), dim3(256), 0,
+                       (hipStream_t)stream, d_tri, num_tri, d_pdef, d_patch_tri, num_patch, d_apex, num_rx, hball,
+                       ro_rx, ro_img, d_masks);
     return (int)hipGetLastError();
 }
 

@@ -101,6 +101,33 @@ typedef struct {
     const unsigned long long *cell_mask;
 } hrt_krxt;
 
+/* ---- patch tables: candidate masks keyed by WHERE A RAY STARTS (host: problem.c patch_build; kernels:
+ * closest_hit_patch, hrt_patch_build_kernel) ----
+ * Every ray of launch b >= 1 starts on the triangle it just hit.  Each triangle carries a (nu x nv) grid
+ * of cells ("patches") in its (e1, e2) basis; per (apex, patch) ONE candidate mask of the whole table,
+ * built once per problem on the device by the packet test itself (packet_culls) with the packet
+ * { origins in the patch's ball, lines that meet ball(apex, ro) }:
+ *   apex k < num_rx            shadow rays towards RX k (they arrive at the apex);
+ *   apex num_rx + tx           the bounce rays of launch 1: they left TX tx and were mirrored by the patch's
+ *                              triangle, so they leave the IMAGE of the TX in that triangle's plane.
+ * A lane finds its patch from its own origin (and is only served when that origin provably lies in the
+ * patch's ball, and -- image apexes -- its line provably meets the apex ball), the wave ORs the masks of
+ * its lanes and walks the union through the staged test: no origin ball, no cone, no culling round, and a
+ * wave whose rays left different surfaces pays for the union of a few small sets, not for the table.
+ * Tables of 65 .. 256 triangles (4 mask words per entry). */
+#define HRT_PATCH_WORDS 4u
+#define HRT_PATCH_MAX_TRI (64u * HRT_PATCH_WORDS)
+#define HRT_PATCH_MARGIN 0.0625f    /* a cell's ball covers this fraction of a cell beyond its outline */
+#define HRT_PATCH_ACCEPT 0.03125f   /* an origin up to this fraction of a cell outside the grid is clamped into it */
+typedef struct {
+    const unsigned long long *mask; /* [num_apex][num_patch][HRT_PATCH_WORDS], or NULL (no tables) */
+    const float *pdef;              /* [T][8]: g1 * nu (xyz), bits(base) | g2 * nv (xyz), bits(nu | nv << 16) */
+    uint32_t num_patch;
+    uint32_t num_img;               /* image-apex tables present for this many TXs (0 or num_tx) */
+    float hmax;                     /* served origins lie within this distance of their triangle's plane */
+    float ro_rx, ro_img;            /* line-point radii the tables were built for */
+} hrt_kpatch;
+
 /* ---- re-sorting of the live list between bounces ----
  * After a bounce the rays of a wave may have left different surfaces in different directions: the
  * wave is then a wide packet and culls nothing.  With `enabled`, the shade kernel writes the
@@ -128,6 +155,7 @@ typedef struct {
     uint32_t num_tri, num_mesh;
     hrt_kaccel acc;
     hrt_krxt rxt;
+    hrt_kpatch patch;
     hrt_ksort sort;
     /* endpoints (device pointers, [n][3]) */
     const float *rx_pos, *tx_pos, *rx_vel, *tx_vel;
@@ -206,6 +234,9 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
 int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_pos, uint32_t num_rx,
                       const float *d_bin_dir4, const float *d_bin_cs2, const float *d_ro_bin,
                       float cx, float cy, float cz, float region_r, unsigned long long *d_masks, void *stream);
+int hrt_hip_patch_build(const float *d_tri, uint32_t num_tri, const float *d_pdef, const uint32_t *d_patch_tri,
+                        uint32_t num_patch, const float *d_apex, uint32_t num_rx, uint32_t num_img, float hball,
+                        float ro_rx, float ro_img, unsigned long long *d_masks, void *stream);
 uint64_t hrt_hip_sort_temp_bytes(uint64_t cap);
 int hrt_hip_sort_hits(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream);
