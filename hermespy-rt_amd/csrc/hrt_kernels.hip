@@ -754,11 +754,44 @@ __device__ __forceinline__ F3 image_of(F3 t, float4 q0, float4 q2)
 // an image apex only if its line passes the apex ball, leaving it.  A served lane contributes the mask of
 // (apex, patch), any other lane of the list the whole table; the wave walks the union through the staged
 // test.  ALL lanes must call (uniform control flow).  apex_k: k (shadow rays to RX k) or num_rx + tx.
+constexpr uint32_t kPatchRxPerUnit = 4u;   // RXs whose shadow rays one unit of the trace kernel traces
+struct PatchRef { bool served; uint32_t off; };   // off: byte offset of the patch's masks inside one apex's table
+template <typename TriPtr>
+__device__ __forceinline__ PatchRef patch_locate(TriPtr tri, const hrt_kpatch &X, uint32_t num_tri, uint32_t htri, F3 o,
+                                                 const bool image, F3 apex, F3 d)
+{
+    PatchRef R = {false, 0u};
+    if (htri < num_tri) {
+        const float4 q0 = tri[HRT_ROW * htri], q2 = tri[HRT_ROW * htri + 2];
+        const float4 p0 = reinterpret_cast<const float4 *>(X.pdef)[2u * htri];
+        const float4 p1 = reinterpret_cast<const float4 *>(X.pdef)[2u * htri + 1u];
+        const F3 sv = sub3(o, {q0.x, q0.y, q0.z});
+        const float fu = fdot3(sv, {p0.x, p0.y, p0.z}), fv = fdot3(sv, {p1.x, p1.y, p1.z});
+        const float hh = fdot3(sv, {q2.y, q2.z, q2.w});
+        const uint32_t bits = __float_as_uint(p1.w), nu = bits & 0xffffu, nv = bits >> 16;
+        // (comparisons written so that a NaN is not served)
+        R.served = (nu != 0u) & (fabsf(hh) <= X.hmax) & (fu >= -HRT_PATCH_ACCEPT) & (fv >= -HRT_PATCH_ACCEPT) &
+                   (fu <= (float)nu + HRT_PATCH_ACCEPT) & (fv <= (float)nv + HRT_PATCH_ACCEPT);
+        if (image) {
+            // the apex of this lane: the image of its TX in ITS triangle's plane; the line must pass
+            // within the radius the tables were built for, leaving the apex (|d| = 1 within 1e-6)
+            const F3 im = image_of(apex, q0, q2);
+            const F3 wv = sub3(o, im);
+            const F3 cx = fcross3(wv, d);
+            R.served &= (fdot3(cx, cx) <= 0.98f * X.ro_img * X.ro_img) && (fdot3(wv, d) > 0.f);
+        }
+        const uint32_t iu = min((uint32_t)max((int)floorf(fu), 0), nu - 1u);
+        const uint32_t iv = min((uint32_t)max((int)floorf(fv), 0), nv - 1u);
+        R.off = (__float_as_uint(p0.w) + iv * nu + iu) * (HRT_PATCH_WORDS * 8u);
+    }
+    return R;
+}
+
+// the trace of a wave whose lanes have located their patches (R; lanes past the end of the list: !valid)
 template <typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__restrict__ orig, const hrt_kpatch &X,
-                                                 uint32_t apex_k, const bool image, F3 apex, uint32_t num_tri,
-                                                 uint32_t htri, F3 o, F3 d, bool valid, uint32_t lane,
-                                                 [[maybe_unused]] int kind)
+                                                 const PatchRef R, uint32_t apex_k, uint32_t num_tri, F3 o, F3 d,
+                                                 bool valid, uint32_t lane, [[maybe_unused]] int kind)
 {
     float best = 1e9f;
     uint32_t who = HRT_NO_HIT, who_o = 0u;
@@ -768,33 +801,9 @@ __device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__r
 #pragma unroll
     for (int k = 0; k < 8; ++k) w[k] = 0u;
     if (valid) {
-        bool served = false;
-        uint32_t off = 0u;
-        if (htri < num_tri) {
-            const float4 q0 = tri[HRT_ROW * htri], q2 = tri[HRT_ROW * htri + 2];
-            const float4 p0 = reinterpret_cast<const float4 *>(X.pdef)[2u * htri];
-            const float4 p1 = reinterpret_cast<const float4 *>(X.pdef)[2u * htri + 1u];
-            const F3 sv = sub3(o, {q0.x, q0.y, q0.z});
-            const float fu = fdot3(sv, {p0.x, p0.y, p0.z}), fv = fdot3(sv, {p1.x, p1.y, p1.z});
-            const float hh = fdot3(sv, {q2.y, q2.z, q2.w});
-            const uint32_t bits = __float_as_uint(p1.w), nu = bits & 0xffffu, nv = bits >> 16;
-            // (comparisons written so that a NaN is not served)
-            served = (nu != 0u) & (fabsf(hh) <= X.hmax) & (fu >= -HRT_PATCH_ACCEPT) & (fv >= -HRT_PATCH_ACCEPT) &
-                     (fu <= (float)nu + HRT_PATCH_ACCEPT) & (fv <= (float)nv + HRT_PATCH_ACCEPT);
-            if (image) {
-                // the apex of this lane: the image of its TX in ITS triangle's plane; the line must pass
-                // within the radius the tables were built for, leaving the apex (|d| = 1 within 1e-6)
-                const F3 im = image_of(apex, q0, q2);
-                const F3 wv = sub3(o, im);
-                const F3 cx = fcross3(wv, d);
-                served &= (fdot3(cx, cx) <= 0.98f * X.ro_img * X.ro_img) && (fdot3(wv, d) > 0.f);
-            }
-            const uint32_t iu = min((uint32_t)max((int)floorf(fu), 0), nu - 1u);
-            const uint32_t iv = min((uint32_t)max((int)floorf(fv), 0), nv - 1u);
-            off = ((apex_k * X.num_patch + __float_as_uint(p0.w)) + iv * nu + iu) * (HRT_PATCH_WORDS * 8u);
-        }
-        if (served) {
+        if (R.served) {
             const Rsrc mr = make_rsrc(reinterpret_cast<const uint8_t *>(X.mask));
+            const uint32_t off = R.off + apex_k * X.num_patch * (HRT_PATCH_WORDS * 8u);
             const auto a = __builtin_amdgcn_raw_buffer_load_b128(mr, (int)off, 0, 0);
             const auto b = __builtin_amdgcn_raw_buffer_load_b128(mr, (int)(off + 16u), 0, 0);
             w[0] = (uint32_t)a[0]; w[1] = (uint32_t)a[1]; w[2] = (uint32_t)a[2]; w[3] = (uint32_t)a[3];
@@ -804,7 +813,7 @@ __device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__r
             for (int k = 0; k < 8; ++k)
                 w[k] = num_tri >= 32u * (uint32_t)(k + 1) ? ~0u : (num_tri > 32u * (uint32_t)k ? (1u << (num_tri - 32u * (uint32_t)k)) - 1u : 0u);
         }
-        HRT_STAT(kind, 6, served ? 1 : 0);
+        HRT_STAT(kind, 6, R.served ? 1 : 0);
     }
     wave_or256(w);
     HRT_STAT(kind, 0, 1);
@@ -1790,10 +1799,11 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
     const uint32_t n_in = first ? P.n0 : counts[b];
     const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
-    // trace kinds of this launch: shadow rays to rx 0..num_rx-1 (k = rx), primary (k = num_rx)
-    const uint32_t k_lo = first ? P.num_rx : 0u;
-    const uint32_t k_hi = (b < P.num_bounces) ? P.num_rx + 1u : P.num_rx;
-    const uint32_t kinds = k_hi - k_lo;
+    // unit types of this launch: the shadow rays (b >= 1), one type per RX (k = rx) -- with patch tables
+    // they are hrt_records_kernel's, not this kernel's -- and the primary rays (b < num_bounces; k = num_rx)
+    const bool psa = VARIANT == 2 && P.patch.mask != nullptr && !first;   // (shadow rays: hrt_records_kernel's)
+    const uint32_t sh_units = (first || psa) ? 0u : P.num_rx;
+    const uint32_t kinds = sh_units + ((b < P.num_bounces) ? 1u : 0u);
     // (static deal: chunks padded to a multiple of 8, see the XCD-aware numbering below)
     constexpr bool kPull = (VARIANT == 6);   // units pulled from a counter (uneven unit costs; on the fine walk
                                              // pulling was measured and lost: 15.7 -> 18.5 ms, the XCD-aware deal matters more)
@@ -1863,25 +1873,25 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         // instead of to `kinds` neighbouring workgroups on different XCDs.  With q = unit / 8 and
         // x = unit % 8: chunk = (q / kinds) * 8 + x, kind = q % kinds (a bijection on the padded range;
         // chunks past the end are skipped).
-        uint32_t chunk, k;
+        uint32_t chunk, kq;   // kq: unit type, shadow types first
         if constexpr (kPull) {
             chunk = unit / kinds;
-            k = k_lo + (unit - chunk * kinds);
+            kq = unit - chunk * kinds;
         } else {
             const uint32_t q = unit >> 3, x = unit & 7u;
             chunk = (q / kinds) * 8u + x;
-            k = k_lo + q % kinds;
+            kq = q % kinds;
             if (chunk >= n_chunks) continue;   // padding of the last group of 8 chunks
         }
         const uint32_t i = chunk * HRT_BLOCK + tid;
         const uint32_t i4 = i * 4u;
         const bool valid = i < n_in;
-        const bool shadow = k < P.num_rx;
+        const bool shadow = kq < sh_units;
+        const uint32_t k = shadow ? kq : P.num_rx;   // (without patch tables: the RX of a shadow unit)
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
         uint32_t tx_lane = 0u, htri = 0u;
         // (patch tables: shadow rays, and the bounce rays of launch 1 -- first-order images of the TXs)
-        const bool patched = VARIANT == 2 && P.patch.mask != nullptr && !first &&
-                             (shadow || (b == 1u && P.patch.num_img != 0u));
+        const bool patched = psa && !shadow && b == 1u && P.patch.num_img != 0u;
         if (valid) {
             if (first) {
                 uint32_t ray;
@@ -1942,10 +1952,11 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         bool done = false;
         if constexpr (VARIANT == 2) {
             if (patched) {
-                F3 pa = apex;   // shadow: the RX; image: the lane's own TX (mirrored per lane)
-                if (!shadow) pa = {P.tx_pos[3 * tx_lane], P.tx_pos[3 * tx_lane + 1], P.tx_pos[3 * tx_lane + 2]};
-                h = closest_hit_patch(tri, P.acc.orig, P.patch, shadow ? k : P.num_rx + tx_lane, !shadow, pa, T, htri, o, d,
-                                      valid, lane, shadow ? 2 : 1);
+                // the apex: the image of the lane's own TX in the plane of the triangle it left
+                const F3 pa = {P.tx_pos[3 * tx_lane], P.tx_pos[3 * tx_lane + 1], P.tx_pos[3 * tx_lane + 2]};
+                PatchRef ref = {false, 0u};
+                if (valid) ref = patch_locate(tri, P.patch, T, htri, o, true, pa, d);
+                h = closest_hit_patch(tri, P.acc.orig, P.patch, ref, P.num_rx + tx_lane, T, o, d, valid, lane, 1);
                 done = true;
             }
         }
@@ -2027,6 +2038,17 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         }
     }
 }
+
+// ===================================================================================
+// RECORDS kernel (patch tables, hrt_kpatch): for launch b >= 1, everything the scatter records of bounce
+// b-1 need -- the shadow traces AND the records (src/compute_paths.c:671-723, quirks Q6-Q8).  A thread
+// takes one entry of the live list: it loads its state, locates its patch ONCE, and walks the RXs IN ORDER:
+// shadow direction, the wave's trace (closest_hit_patch: the masks of the lanes' patches ORed, the union
+// walked through the staged test), theta carried through the shadow hits, the record.  Nothing of a packet
+// is formed -- no origin ball, no cone, no culling round -- so the cost does not depend on how coherent the
+// wave is; and the shadow direction is computed once, not once per kernel, with no result words in between.
+// Defined behind the shading functions (below).
+// ===================================================================================
 
 // ===================================================================================
 // WIDE kernels (big tables, behind the trace kernel of the fine walk): the packets that were too wide to
@@ -2402,8 +2424,8 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
             pt = ldf(res_blk(P, P.num_rx), cap4, i4);
         }
 
-        // ---- scatter records of bounce b-1 ----
-        if (!first) {
+        // ---- scatter records of bounce b-1 (unless hrt_records_kernel wrote them) ----
+        if (!first && !P.records_done) {
             const uint32_t pb = b - 1;
             F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
             float mat_s = 0.f, mat_alpha = 1.f;
@@ -2590,6 +2612,111 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     }
 }
 
+#ifndef HRT_RECORDS_WAVES
+#define HRT_RECORDS_WAVES 6
+#endif
+// LDS: [T x 5 float4 rows][num_rx RX pos][17 x 4 float4 materials]
+__global__ __launch_bounds__(HRT_BLOCK, HRT_RECORDS_WAVES) void hrt_records_kernel(const hrt_kparams P, const uint32_t b)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    const uint32_t n_in = counts[b];
+    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
+    if (blockIdx.x >= n_chunks) return;
+    const uint32_t T = P.num_tri;
+    const uint32_t cap4 = (uint32_t)P.cap * 4u;
+    const Rsrc mesh_r = make_rsrc(reinterpret_cast<const uint8_t *>(P.mesh));
+    float4 *l_tri = lds;
+    float4 *l_rx = lds + HRT_ROW * T;
+    float4 *l_mat = l_rx + P.num_rx;
+    {
+        const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+        const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
+        for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
+        for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
+            l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
+        for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) l_mat[k] = g_mat[k];
+    }
+    __syncthreads();
+    const float4 *tri = l_tri;
+    const uint32_t pb = b - 1;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t i = chunk * HRT_BLOCK + tid;
+        const uint32_t i4 = i * 4u;
+        const bool valid = i < n_in;
+        F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f}, n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
+        float theta = 0.f, tau = 0.f, a0 = 1.f, a1 = 0.f, a2 = 1.f, a3 = 0.f, mat_s = 0.f, mat_alpha = 1.f;
+        PatchRef ref = {false, 0u};
+        if (valid) {
+            const uint32_t htri = ldu(hit_blk(P, pb), H_TRI * cap4, i4);
+            theta = ldf(hit_blk(P, pb), H_THETA * cap4, i4);
+            o = {ldf(hit_blk(P, pb), H_OX * cap4, i4), ldf(hit_blk(P, pb), H_OY * cap4, i4),
+                 ldf(hit_blk(P, pb), H_OZ * cap4, i4)};
+            d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4),
+                 ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
+            a0 = ldf(hit_blk(P, pb), H_A0 * cap4, i4);
+            a1 = ldf(hit_blk(P, pb), H_A1 * cap4, i4);
+            a2 = ldf(hit_blk(P, pb), H_A2 * cap4, i4);
+            a3 = ldf(hit_blk(P, pb), H_A3 * cap4, i4);
+            tau = ldf(hit_blk(P, pb), H_TAU * cap4, i4);
+            ref = patch_locate(tri, P.patch, T, htri, o, false, o, o);
+            if (htri < T) {   // (always: the list holds rows of the table; never fault)
+                const float4 q2 = tri[HRT_ROW * htri + 2];
+                n = {q2.y, q2.z, q2.w};
+                const float4 mm = gather4(mesh_r, HRT_MESH_FLOATS * 4u, __float_as_uint(tri[HRT_ROW * htri + 4].w), 0u);
+                mvel = {mm.x, mm.y, mm.z};
+                const float4 m3 = l_mat[4u * __float_as_uint(mm.w) + 3u];
+                mat_s = m3.x;
+                mat_alpha = m3.y;
+            }
+        }
+        for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
+            const float4 rp = l_rx[rx];
+            float d2rx;
+            F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
+            if (!valid) w = {0.f, 0.f, 1.f};
+            const Hit h = closest_hit_patch(tri, P.acc.orig, P.patch, ref, rx, T, o, w, valid, lane, 2);
+            bool unblocked = false;
+            if (valid) {
+                if (h.tri != HRT_NO_HIT) {   // quirk Q7: any shadow hit, at any distance, overwrites theta
+                    const float4 q2 = tri[HRT_ROW * h.tri + 2];
+                    theta = incidence_angle({q2.y, q2.z, q2.w}, w);
+                }
+                if (h.tri != HRT_NO_HIT && h.t <= 1.f) {   // quirk Q6: blocked within one metre
+                    stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, 0.f);
+                    stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, 0.f);
+                    stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, 0.f);
+                    stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, 0.f);
+                    stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, 0.f);
+                } else {
+                    unblocked = true;
+                    const float th_s = acos_f_ool(dot3(w, n));
+                    const float4 S = scatter_pattern(mat_s, mat_alpha, th_s, theta);
+                    float o0 = a0 * S.x - a1 * S.y;
+                    float o1 = a0 * S.y + a1 * S.x;
+                    float o2 = a2 * S.z - a3 * S.w;
+                    float o3 = a2 * S.w + a3 * S.z;
+                    float f2 = P.fsl_mult * d2rx;
+                    f2 *= f2;
+                    if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
+                    stf(rec_blk(P, pb, rx), R_A0 * cap4, i4, o0);
+                    stf(rec_blk(P, pb, rx), R_A1 * cap4, i4, o1);
+                    stf(rec_blk(P, pb, rx), R_A2 * cap4, i4, o2);
+                    stf(rec_blk(P, pb, rx), R_A3 * cap4, i4, o3);
+                    stf(rec_blk(P, pb, rx), R_TAU * cap4, i4, tau + d2rx / kC);
+                    stf(rec_blk(P, pb, rx), R_DX * cap4, i4, -w.x);
+                    stf(rec_blk(P, pb, rx), R_DY * cap4, i4, -w.y);
+                    stf(rec_blk(P, pb, rx), R_DZ * cap4, i4, -w.z);
+                    stf(rec_blk(P, pb, rx), R_DFS * cap4, i4, dot3(sub3(w, d), mvel) * P.dop_mult);
+                }
+            }
+            const unsigned long long m = __ballot(unblocked);
+            if (lane == 0 && valid) mask_words(P, pb, rx)[i >> 6] = m;
+        }
+    }
+}
+
 // ===================================================================================
 // FUSED kernels: one launch = ONE kernel (trace + shading + stable compaction).
 //
@@ -2668,7 +2795,9 @@ __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chun
         const bool ok_c = HRT_BALLOT(!(cw & kLbDone)) == 0ull, ok_g = HRT_BALLOT(!(gw & kLbDone)) == 0ull;
         const bool ok_s = HRT_BALLOT(!(s0 & s1 & kLbDone)) == 0ull;
         uint32_t sum_c = 0u, sum_g = 0u;
-        if (ok_c && (g_owed || (ok_g && ok_s))) sum_c = wave_sum_u32(cw & ~kLbDone);
+        // (sum_c is formed whenever it is consumed below: by the group word, by the supergroup word --
+        // which may be owed while super[sg - 1] is still missing -- or by the result)
+        if (ok_c && (g_owed || (ok_g && (s_owed || ok_s)))) sum_c = wave_sum_u32(cw & ~kLbDone);
         if (ok_c && g_owed) {
             if (lane == 0) lb_store(W.group + g, kLbDone | (sum_c + c));
             g_owed = false;
@@ -3906,6 +4035,22 @@ static bool walks_fine(const hrt_kparams *P)
     return !in_lds && !trees && P->acc.fine != nullptr && (variant == 7 || variant == 9);
 }
 
+// patch tables on a table that takes the small-table packet kernel: shadow traces + records of launch
+// `bounce` >= 1 are hrt_records_kernel's (launched by hrt_hip_launch_trace), the shade kernel skips them
+static bool records_in_own_kernel(const hrt_kparams *P, uint32_t bounce)
+{
+    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
+    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const uint64_t T = P->num_tri;
+    const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
+                               (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
+    const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
+    const bool one_block = P->num_tri <= kMaskRounds * 64u;
+    const bool trees = P->acc.big && (variant >= 4) && variant != 9;
+    const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
+    return bounce != 0 && P->patch.mask != nullptr && in_lds && flat && one_block && !walks_fine(P);
+}
+
 // geometry of launch `bounce`: the trace kernel (all shadow + primary traces of the live list)
 int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
 {
@@ -3957,7 +4102,20 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
         if (variant == 0) launch_trace_t<true, 0>(P, bounce, nb, lds, st, &err);
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
         else if (flat) {
-            if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
+            if (records_in_own_kernel(P, bounce)) {
+                // patch tables: shadow traces + records are hrt_records_kernel's, the trace kernel keeps the primary rays
+                uint64_t rblocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
+                if (rblocks > 2u * max_grid) rblocks = 2u * max_grid;
+                const size_t rlds = (size_t)T * HRT_TRI_FLOATS * 4u + (size_t)P->num_rx * 16u +
+                                    (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u);
+                if (rlds > 64u * 1024u) return (int)hipErrorInvalidValue;   // (cannot happen: T <= HRT_PATCH_MAX_TRI)
+                hipLaunchKernelGGL(hrt_records_kernel, dim3((uint32_t)rblocks), dim3(HRT_BLOCK), rlds, st, *P, bounce);
+                if (bounce < P->num_bounces) {
+                    uint64_t pblocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
+                    if (pblocks > max_grid) pblocks = max_grid;
+                    launch_trace_t<true, 2>(P, bounce, (uint32_t)pblocks, lds, st, &err);
+                }
+            } else if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
             else launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
         } else if (trees) launch_trace_t<true, 6>(P, bounce, nb, lds, st, &err);
         else if (one_block) launch_trace_t<true, 4>(P, bounce, nb, lds, st, &err);
@@ -3978,6 +4136,8 @@ int hrt_hip_launch_shade(const hrt_kparams *P_in, uint32_t bounce, void *stream)
 {
     hrt_kparams Pc = *P_in;
     Pc.cnt_per_wave = walks_fine(P_in) ? 1u : 0u;
+    Pc.records_done = records_in_own_kernel(P_in, bounce) ? 1u : 0u;
+    if (Pc.records_done && bounce >= Pc.num_bounces) return 0;   // the last launch: records only, nothing left to shade
     const hrt_kparams *P = &Pc;
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
     uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;

@@ -184,6 +184,7 @@ typedef struct {
     uint32_t los_blocks;  /* fused launch 0: the last los_blocks workgroups of the grid do the LoS pass (0: own kernel) */
     uint32_t phase_bounce;   /* -DHRT_PHASE_STATS builds: the launch whose workgroups record their time stamps */
     uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
+    uint32_t records_done; /* set by the shade shim: hrt_records_kernel wrote this launch's records (patch tables) */
     /* queue of the packets that are too wide to cull (big tables, hrt_wide_kernel): wide_cap entries of
      * 8 bytes at off_wide_q, 64 keys of 8 bytes per entry at off_wide_key; the per-launch entry counts are
      * the u32 at off_counts + HRT_CNT_WIDE + 4 b (zeroed with the counts).  wide_cap 0: no queue */
