@@ -73,6 +73,8 @@ struct hrt_problem {
     void *d_rxt;                 /* per-RX direction tables (device blob), or NULL */
     hrt_krxt krxt;
     uint64_t rxt_entries;        /* total list entries over all (rx, cell) */
+    void *aux_stream;            /* second stream of a trace: the records kernels run beside the bounce kernels */
+    void *aux_ev[2];             /* fork (live list complete) / join (records done): ordering-only events */
     void *d_patch;               /* patch tables (device blob), or NULL */
     hrt_kpatch kpatch;
     int sort_rays;               /* re-sort the live list between bounces (hrt_ksort) */

@@ -72,6 +72,8 @@ void hrt_problem_destroy(hrt_problem *p)
         hrt_hip_free(p->d_blob);
         if (p->d_rxt) hrt_hip_free(p->d_rxt);
         if (p->d_patch) hrt_hip_free(p->d_patch);
+        if (p->aux_stream) hrt_hip_stream_destroy(p->aux_stream);
+        for (int k = 0; k < 2; ++k) if (p->aux_ev[k]) hrt_hip_event_destroy(p->aux_ev[k]);
     }
     free(p->h_tri); free(p->h_mesh); free(p->h_mat); free(p->h_tri_mesh); free(p->h_tri_face);
     hrt_accel_free(&p->accel);
@@ -1225,6 +1227,21 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
 
     HRT_HIP(hrt_hip_set_device(p->device), "hipSetDevice");
     const uint32_t nb = s->num_bounces;
+    /* the second stream (created with the first trace that can use it; HRT_OVERLAP=0: one stream) */
+    hrt_problem *pp = (hrt_problem *)p;
+    int aux = 0, forked = 0;
+    if (p->kpatch.mask) {
+        const char *ov = getenv("HRT_OVERLAP");
+        if (!(ov && *ov == '0')) {
+            if (!pp->aux_stream) {
+                int e2;
+                if ((e2 = hrt_hip_stream_create(&pp->aux_stream)) || (e2 = hrt_hip_event_create_sync(&pp->aux_ev[0])) ||
+                    (e2 = hrt_hip_event_create_sync(&pp->aux_ev[1])))
+                    return hrt_fail_hip(e2, "hipStreamCreate(records stream)");
+            }
+            aux = 1;
+        }
+    }
     /* events (only with a timer): [0,1] around LoS; per launch b: start, end of trace (= start
      * of scan), end of scan (= start of shade), end of shade */
     void **ev = timer ? timer->ev : NULL;
@@ -1242,9 +1259,33 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     if (ev) STEP(hrt_hip_event_record(ev[1], stream));
     for (uint32_t b = 0; b <= nb; ++b) {
         if (ev) STEP(hrt_hip_event_record(ev[2 + 4 * b], stream));
+        /* Patch tables: the records of bounce b-1 (shadow traces + records, hrt_records_kernel) need only the
+         * live list of this launch, and nothing of this launch needs them: they run on the problem's second
+         * stream, beside the bounce's own kernels (a VALU-bound kernel beside latency-bound ones), forked and
+         * joined by events.  With a timer everything stays on one stream, so that the per-kernel times mean
+         * what they say. */
+        int own_records = 0;
+        if (b >= 1 && !hip) {
+            void *rs = stream;
+            if (aux && !ev) {
+                STEP(hrt_hip_event_record(pp->aux_ev[0], stream));
+                STEP(hrt_hip_stream_wait_event(pp->aux_stream, pp->aux_ev[0]));
+                rs = pp->aux_stream;
+            }
+            const int rr = hip ? 0 : hrt_hip_launch_records(&K, b, rs);   /* -1: not this problem */
+            if (rr > 0) hip = rr;
+            if (rr == 0) own_records = 1;
+            if (rr == 0 && rs != stream) forked = 1;
+        }
+        if (own_records && b == nb) {   /* the last launch: records only */
+            if (ev) { STEP(hrt_hip_event_record(ev[3 + 4 * b], stream)); STEP(hrt_hip_event_record(ev[5 + 4 * b], stream)); }
+            continue;
+        }
         /* one kernel for the whole launch (trace + shading + stable compaction) where that is what the
-         * launch wants: launch 0 always, every launch on tables of one culling round; then the
-         * "trace" time is the fused kernel's and the "shade" time zero */
+         * launch wants: launch 0 always, every launch on tables of one culling round; then the "trace" time is
+         * the fused kernel's and the "shade" time zero.  (Patch tables, records in their own kernel: the bounce
+         * alone as one fused kernel was measured and lost -- C3 1.21 -> 1.40 ms: at 118 registers the packet walk
+         * runs at 4 waves per SIMD, and its spinning waves keep the records kernel from overlapping.) */
         const int fused = b == 0 ? (K.fuse & HRT_FUSE_LAUNCH0) != 0 : (K.fuse & HRT_FUSE_BOUNCES) != 0;
         int fused_rc = -1;
         if (fused && !hip) fused_rc = hrt_hip_launch_fused(&K, b, stream);   /* -1: this table / variant is not fusable */
@@ -1264,6 +1305,10 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
         STEP(hrt_hip_launch_shade(&K, b, stream));
         if (p->sort_rays && b < nb) STEP(hrt_hip_sort_hits(&K, b, stream));   /* part of the "shade" time */
         if (ev) STEP(hrt_hip_event_record(ev[5 + 4 * b], stream));
+    }
+    if (forked) {   /* join: the caller's stream continues behind the last records kernel */
+        STEP(hrt_hip_event_record(pp->aux_ev[1], pp->aux_stream));
+        STEP(hrt_hip_stream_wait_event(stream, pp->aux_ev[1]));
     }
 #undef STEP
     if (timer) timer->recorded = !hip;

@@ -754,7 +754,6 @@ __device__ __forceinline__ F3 image_of(F3 t, float4 q0, float4 q2)
 // an image apex only if its line passes the apex ball, leaving it.  A served lane contributes the mask of
 // (apex, patch), any other lane of the list the whole table; the wave walks the union through the staged
 // test.  ALL lanes must call (uniform control flow).  apex_k: k (shadow rays to RX k) or num_rx + tx.
-constexpr uint32_t kPatchRxPerUnit = 4u;   // RXs whose shadow rays one unit of the trace kernel traces
 struct PatchRef { bool served; uint32_t off; };   // off: byte offset of the patch's masks inside one apex's table
 template <typename TriPtr>
 __device__ __forceinline__ PatchRef patch_locate(TriPtr tri, const hrt_kpatch &X, uint32_t num_tri, uint32_t htri, F3 o,
@@ -3116,8 +3115,8 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
     }
     HRT_PHASE(10);
 
-    // ---- (3) scatter records of bounce b-1: shadow ray to every RX, in order ----
-    if constexpr (!FIRST) {
+    // ---- (3) scatter records of bounce b-1: shadow ray to every RX, in order (unless hrt_records_kernel's) ----
+    if constexpr (!FIRST) if (!P.records_done) {
         const uint32_t pb = b - 1;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -4103,13 +4102,8 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
         else if (variant == 1) launch_trace_t<true, 1>(P, bounce, nb, lds, st, &err);
         else if (flat) {
             if (records_in_own_kernel(P, bounce)) {
-                // patch tables: shadow traces + records are hrt_records_kernel's, the trace kernel keeps the primary rays
-                uint64_t rblocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
-                if (rblocks > 2u * max_grid) rblocks = 2u * max_grid;
-                const size_t rlds = (size_t)T * HRT_TRI_FLOATS * 4u + (size_t)P->num_rx * 16u +
-                                    (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u);
-                if (rlds > 64u * 1024u) return (int)hipErrorInvalidValue;   // (cannot happen: T <= HRT_PATCH_MAX_TRI)
-                hipLaunchKernelGGL(hrt_records_kernel, dim3((uint32_t)rblocks), dim3(HRT_BLOCK), rlds, st, *P, bounce);
+                // patch tables: shadow traces + records are hrt_records_kernel's (hrt_hip_launch_records), this
+                // kernel keeps the primary rays
                 if (bounce < P->num_bounces) {
                     uint64_t pblocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
                     if (pblocks > max_grid) pblocks = max_grid;
@@ -4128,6 +4122,22 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
         else launch_trace_t<false, 5>(P, bounce, nb, lds, st, &err);   // tables beyond LDS are > 1 block
     }
     if (err != hipSuccess) return (int)err;
+    return (int)hipGetLastError();
+}
+
+// shadow traces + scatter records of launch `bounce` >= 1 as their own kernel (patch tables); -1: not this
+// problem / launch (then the trace and shade kernels do that work), nothing launched
+int hrt_hip_launch_records(const hrt_kparams *P, uint32_t bounce, void *stream)
+{
+    if (!records_in_own_kernel(P, bounce)) return -1;
+    static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
+    const uint64_t T = P->num_tri;
+    uint64_t rblocks = (P->cap + HRT_BLOCK - 1) / HRT_BLOCK;
+    if (rblocks > 2u * max_grid) rblocks = 2u * max_grid;   // (1 024 .. 4 096 workgroups: 2-5 % slower)
+    const size_t rlds = (size_t)T * HRT_TRI_FLOATS * 4u + (size_t)P->num_rx * 16u +
+                        (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u);
+    if (rlds > 64u * 1024u) return (int)hipErrorInvalidValue;   // (cannot happen: T <= HRT_PATCH_MAX_TRI)
+    hipLaunchKernelGGL(hrt_records_kernel, dim3((uint32_t)rblocks), dim3(HRT_BLOCK), rlds, (hipStream_t)stream, *P, bounce);
     return (int)hipGetLastError();
 }
 
@@ -4161,6 +4171,7 @@ int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
 #ifdef HRT_PHASE_STATS
     Pc.phase_bounce = (uint32_t)env_u64("HRT_PHASE_BOUNCE", 0);
 #endif
+    Pc.records_done = records_in_own_kernel(P_in, bounce) ? 1u : 0u;
     if (bounce != 0) Pc.los_blocks = 0;
     else if (Pc.los_blocks) Pc.los_blocks = (Pc.num_rx * Pc.num_tx + HRT_BLOCK / 64u - 1u) / (HRT_BLOCK / 64u);
     const hrt_kparams *P = &Pc;
@@ -4358,6 +4369,17 @@ int hrt_hip_event_create(void **ev)
     const int rc = (int)hipEventCreate(&e);
     *ev = (void *)e;
     return rc;
+}
+int hrt_hip_event_create_sync(void **ev)   /* ordering only (no time stamps): cheaper to record */
+{
+    hipEvent_t e;
+    const int rc = (int)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    *ev = (void *)e;
+    return rc;
+}
+int hrt_hip_stream_wait_event(void *stream, void *ev)
+{
+    return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
 }
 int hrt_hip_event_destroy(void *ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
 int hrt_hip_event_record(void *ev, void *stream)

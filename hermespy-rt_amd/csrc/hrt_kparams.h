@@ -229,6 +229,9 @@ int hrt_hip_launch_trace(const hrt_kparams *P, uint32_t bounce, void *stream);
 int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
 
 int hrt_hip_launch_fused(const hrt_kparams *P, uint32_t bounce, void *stream);   /* -1: not fusable, nothing launched */
+int hrt_hip_launch_records(const hrt_kparams *P, uint32_t bounce, void *stream); /* -1: not applicable, nothing launched */
+int hrt_hip_event_create_sync(void **ev);
+int hrt_hip_stream_wait_event(void *stream, void *ev);
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,
                         uint64_t num_local, float *d_dirs, uint32_t *d_fix_count,
                         uint32_t *d_fix_list, uint32_t fix_cap, void *stream);
