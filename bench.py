@@ -137,10 +137,10 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def dropin_once(c, lib_, abi, W):
+def dropin_once(c, lib_, abi, W, with_rays=False):
     st = lib_.Stats()
     t0 = time.time()
-    abi.run_compute_paths(lib_.load(), *W.args(c), with_rays=False, stats=st)
+    abi.run_compute_paths(lib_.load(), *W.args(c), with_rays=with_rays, stats=st)
     wall = time.time() - t0
     paths = int(st.records) + len(c["rx_pos"]) * len(c["tx_pos"])
     host_bytes = 4 * 9 * len(c["rx_pos"]) * len(c["tx_pos"]) * c["num_bounces"] * c["num_paths"]
@@ -455,13 +455,18 @@ def main():
             torch.cuda.empty_cache()
             cold = dropin_once(base, _lib, abi, W)
             warm = dropin_once(base, _lib, abi, W)
+            # ... and the literal call of inc/compute_paths.h:59-74 as the reference's own callers make it
+            # (test/test.c:56-72, compute_paths_pybind11.cpp:149-170): RaysInfo snapshots requested too
+            with_rays = dropin_once(base, _lib, abi, W, with_rays=True)
+            with_rays = dropin_once(base, _lib, abi, W, with_rays=True)
             out["end_to_end"] = dict(
                 what="hrt_compute_paths_ex (the drop-in C ABI behind compute_paths): host arrays in, the "
                      "reference's dense arrays out; cold = first call in this process after the bench "
-                     "(HIP already initialised), warm = second call; python_module_s = wall of "
-                     "hermespy_rt.compute_paths() (the pybind11 drop-in: array allocation, the call, complex "
-                     "amplitudes), second and third call",
-                cold=cold, warm=warm)
+                     "(HIP already initialised), warm = second call; with_raysinfo = the warm call with the "
+                     "RaysInfo snapshots requested as every caller of the reference does (second such call); "
+                     "python_module_s = wall of hermespy_rt.compute_paths() (the pybind11 drop-in: array "
+                     "allocation, the call, complex amplitudes), second and third call",
+                cold=cold, warm=warm, with_raysinfo=with_rays)
             try:   # the Python surface HermesPy imports
                 import hermespy_rt_amd as _pkg
                 if _pkg.LIB_DIR not in sys.path:

@@ -368,11 +368,12 @@ int hrt_worker_alloc(dev_ctx *c)
             w->device = c->device;
             /* per-call host arrays are not pooled; the small ones sized by nrx / ntx are re-made */
             w->h_dirs = NULL; w->cur_rays = NULL; w->active = w->next_active = NULL; w->dirs_batch = NULL;
-            free(w->h_los); free(w->run_start); free(w->run_tx);
+            free(w->h_los); free(w->run_start); free(w->run_tx); free(w->h_counts);
+            w->h_counts = (uint32_t *)calloc(nb + 4, 4);
             w->h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
             w->run_start = (uint64_t *)malloc((ntx + 2) * sizeof(uint64_t));
             w->run_tx = (uint32_t *)malloc((ntx + 1) * sizeof(uint32_t));
-            if (!w->h_los || !w->run_start || !w->run_tx) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+            if (!w->h_los || !w->run_start || !w->run_tx || !w->h_counts) return hrt_fail(HRT_E_NOMEM, "out of host memory");
             return HRT_OK;
         }
         if (ps->valid) { work_free(&ps->w); memset(ps, 0, sizeof *ps); }
@@ -383,7 +384,7 @@ int hrt_worker_alloc(dev_ctx *c)
     if ((rc = hrt_device_malloc(w->device, &w->d_dirs, (n_loc_max + 64) * 12))) return rc;   /* + rounding of a prefill piece */
     if ((rc = hrt_device_malloc(w->device, &w->d_order, (n_loc_max + 64) * 4))) return rc;
     w->h_order = (uint32_t *)malloc((n_loc_max + 64) * 4);
-    w->h_counts = (uint32_t *)calloc(34 + 2, 4);
+    w->h_counts = (uint32_t *)calloc(c->nb + 4, 4);
     w->h_los = (float *)malloc(nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
     w->run_start = (uint64_t *)malloc((ntx + 2) * sizeof(uint64_t));
     w->run_tx = (uint32_t *)malloc((ntx + 1) * sizeof(uint32_t));
@@ -492,7 +493,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
     {
         hrt_stats bs;
         hrt_work_from_counts(prob, &s, w->h_counts, &bs);
-        for (size_t b = 0; b <= nb; ++b) st->live[b] += bs.live[b];
+        for (size_t b = 0; b <= nb && b < 34; ++b) st->live[b] += bs.live[b];
         st->records += bs.records;
         st->tests += bs.tests - (g ? (uint64_t)nrx * ntx * T : 0);   /* LoS counted once */
     }
@@ -541,6 +542,32 @@ static int run_batch(dev_ctx *c, uint32_t g)
      * With one TX (one run per bounce) the NEXT bounce is started while the last block of this one is
      * written: its rays and triangles and its first record block are requested then (`pre`), so no
      * copy is waited for with the writer idle except the very first. */
+    if (scat_rays) {
+        /* :589 -- the launch block [tx][p] = {tx_pos, direction}, this batch's paths; and the batch's ray
+         * states (the directions of a device-generated launch set are fetched from d_dirs) */
+        const float *dsrc;
+        if (c->host_launch) dsrc = (G > 1) ? w->dirs_batch : w->h_dirs;
+        else {
+            if (!w->dirs_batch) w->dirs_batch = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
+            if (!w->dirs_batch) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            if ((rc = hrt_device_download(w->device, w->dirs_batch, w->d_dirs, n_loc * 12))) goto done;
+            dsrc = w->dirs_batch;
+        }
+        if (!w->cur_rays) w->cur_rays = (Ray *)malloc(ntx * hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * sizeof(Ray));
+        if (!w->cur_rays) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+        const uint32_t ch = s.chunk ? s.chunk : 4096u;
+        for (size_t tx = 0; tx < ntx; ++tx) {
+            for (uint64_t il = 0; il < n_loc; ++il) {
+                Ray *r = &w->cur_rays[tx * n_loc + il];
+                r->o = tx_pos[tx];
+                memcpy(&r->d, dsrc + 3 * il, sizeof(Vec3));
+            }
+            for (uint64_t il = 0; il < n_loc; il += ch) {
+                const uint64_t len = n_loc - il < ch ? n_loc - il : ch;
+                memcpy(scat_rays->rays + tx * np + hrt_shard_global_path(&s, il), w->cur_rays + tx * n_loc + il, len * sizeof(Ray));
+            }
+        }
+    }
     const int can_pre = (ntx == 1) && !scat_rays && !env_int("HRT_NO_BOUNCE_PREFETCH", 0);
     /* slim records (default; HRT_FULL_RECORDS=1 copies all nine fields): see scatter_ctx */
     const int slim = !env_int("HRT_FULL_RECORDS", 0);
@@ -672,32 +699,36 @@ static int run_batch(dev_ctx *c, uint32_t g)
         }
 #undef FETCH_RX
 
-        /* ---- RaysInfo snapshots (:732-743) ---- */
-        if (scat_rays && G == 1) {
-            memset(w->next_active, 0, nq / 8);           /* bits >= nq keep their ones */
-            w->next_active[nq / 8] = w->active[nq / 8];
-            for (size_t q = nq - nq % 8; q < nq; ++q) w->next_active[q / 8] &= (uint8_t)~(1u << (q % 8));
+        /* ---- RaysInfo snapshots (:732-743), this batch's paths.  The state of a ray after bounce b goes
+         * to slot (tx * nb + b + 1) * np + p whether it hit or not (Q14: dead rays keep their last state), so
+         * a snapshot depends on that ray's history alone: every batch writes the slots of its own paths
+         * (granule by granule), on whatever device it ran.  The active bits go into the shared per-bounce
+         * bit strings; the reference's copies of them (Q12) are made once all batches are done. ---- */
+        if (scat_rays) {
+            uint8_t *act = c->act_all + (b + 1) * (nq / 8 + 1);
+            const uint32_t ch = s.chunk ? s.chunk : 4096u;
             for (uint64_t i = 0; i < H; ++i) {
-                const uint32_t q = w->ray[i];            /* one batch: local id == tx*np+p */
-                w->next_active[q / 8] |= (uint8_t)(1u << (q % 8));
-                Ray *r = &w->cur_rays[q];
+                const uint32_t ql = w->ray[i];           /* tx * n_loc + local path */
+                const uint64_t tx = ql / n_loc, il = ql - tx * n_loc;
+                const uint64_t p = hrt_shard_global_path(&s, il);
+                const uint64_t q = tx * np + p;
+                /* bytes shared with another batch's paths (a TX boundary that is not a multiple of 8, the
+                 * ends of a granule) are updated atomically; the rest of a granule's bytes are this batch's */
+                const uint64_t g0 = tx * np + p / ch * ch, g1 = tx * np + (p / ch * ch + ch < np ? p / ch * ch + ch : np);
+                const uint8_t bit = (uint8_t)(1u << (q % 8));
+                if (q / 8 > g0 / 8 && q / 8 < (g1 - 1) / 8) act[q / 8] |= bit;
+                else __atomic_fetch_or(&act[q / 8], bit, __ATOMIC_RELAXED);
+                Ray *r = &w->cur_rays[ql];
                 r->o = (Vec3){w->st[0][i], w->st[1][i], w->st[2][i]};
                 r->d = (Vec3){w->st[3][i], w->st[4][i], w->st[5][i]};
             }
-            const size_t nbytes = np / 8 + 1;
             for (size_t tx = 0; tx < ntx; ++tx) {
-                const size_t off_rays = (tx * nb + (b + 1)) * np;
-                const size_t off_act = (tx * nb + (b + 1)) * nbytes;
-                memcpy(scat_rays->rays + off_rays, w->cur_rays + tx * np, np * sizeof(Ray));
-                uint8_t *dst = scat_rays->rays_active + off_act;
-                memcpy(dst, w->next_active, nbytes);
-                if (tx == 0 && ntx > 1)   /* Q12: tx1's first bits are still last bounce's */
-                    for (size_t bitp = np; bitp < 8 * nbytes; ++bitp) {
-                        uint8_t m = (uint8_t)(1u << (bitp % 8));
-                        dst[bitp / 8] = (uint8_t)((dst[bitp / 8] & ~m) | (w->active[bitp / 8] & m));
-                    }
+                Ray *dst = scat_rays->rays + (tx * nb + (b + 1)) * np;
+                for (uint64_t il = 0; il < n_loc; il += ch) {
+                    const uint64_t len = n_loc - il < ch ? n_loc - il : ch;
+                    memcpy(dst + hrt_shard_global_path(&s, il), w->cur_rays + tx * n_loc + il, len * sizeof(Ray));
+                }
             }
-            uint8_t *sw = w->active; w->active = w->next_active; w->next_active = sw;
         }
     }
     c->t_rb += hrt_now_s() - t0;
@@ -751,14 +782,12 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
     const double t_begin = hrt_now_s();
     if (!scene || !los || !scat) return hrt_fail(HRT_E_INVALID, "compute_paths: NULL argument");
     if (np == 0 || nb == 0) return hrt_fail(HRT_E_INVALID, "num_rays and num_bounces must be > 0");
-    if (nb > 32) return hrt_fail(HRT_E_INVALID, "num_bounces > 32 is not supported");
+    if (nb > 65535) return hrt_fail(HRT_E_INVALID, "num_bounces > 65535 is not supported");
 
     hrt_stats st;
     memset(&st, 0, sizeof st);
     int devs[HRT_MAX_DEVICES];
     int D = parse_devices(devs);
-    /* RaysInfo snapshots copy the state of EVERY ray after each bounce: one batch, one device */
-    if (scat_rays) D = 1;
     dev_ctx *ctx = (dev_ctx *)calloc((size_t)D, sizeof(dev_ctx));
     if (!ctx) return hrt_fail(HRT_E_NOMEM, "out of host memory");
     const int D_created = D;   /* a problem is made for each of these, however many end up with work */
@@ -819,7 +848,7 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
             budget /= (uint64_t)(same > 0 ? same : 1);
         }
         hrt_layout L;
-        for (; !scat_rays;) {
+        for (;;) {
             hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
             rc = hrt_layout_query(prob, &s, &L);
             if (rc == HRT_OK && G >= (uint32_t)D && L.total_bytes + hrt_shard_num_local(&s) * 12 <= budget) break;
@@ -895,11 +924,6 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
                     if ((rc = hrt_device_download(w->device, scat->freq_shift + tx * np * nb + a, w->d_ws, n_p * 4))) goto done;
                 }
             }
-            if (scat_rays) {   /* RaysInfo needs the directions on the host (one batch: they are in d_dirs) */
-                w->h_dirs = (float *)malloc(np * 3 * sizeof(float));
-                if (!w->h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
-                if ((rc = hrt_device_download(w->device, w->h_dirs, w->d_dirs, np * 12))) goto done;
-            }
         }
         st.t_launch_dirs_s = hrt_now_s() - t0;
         /* Q9: the two memcpy replications of the launch term (source and destinations never overlap:
@@ -917,23 +941,15 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
         }
 
         if (scat_rays) {
-            /* :469-471 and :589 */
-            for (size_t i = 0; i < nq / 8 + 1; ++i) scat_rays->rays_active[i] = 0xff;
-            w->cur_rays = (Ray *)malloc(nq * sizeof(Ray));
-            w->active = (uint8_t *)malloc(nq / 8 + 1);
-            w->next_active = (uint8_t *)malloc(nq / 8 + 1);
-            if (!w->cur_rays || !w->active || !w->next_active) {
-                rc = hrt_fail(HRT_E_NOMEM, "out of host memory");
-                goto done;
-            }
-            memset(w->active, 0xff, nq / 8 + 1);
-            for (size_t tx = 0; tx < ntx; ++tx)
-                for (size_t p = 0; p < np; ++p) {
-                    Ray *r = &w->cur_rays[tx * np + p];
-                    r->o = tx_pos[tx];
-                    memcpy(&r->d, w->h_dirs + 3 * p, sizeof(Vec3));
-                }
-            memcpy(scat_rays->rays, w->cur_rays, nq * sizeof(Ray));
+            /* :469-471: all rays active before bounce 0; the bit strings after bounce 0 .. nb-1 start empty
+             * (the bits beyond nq in the last byte are never cleared by the reference: they stay set) */
+            const size_t nbq = nq / 8 + 1;
+            uint8_t *act = (uint8_t *)calloc(nb + 1, nbq);
+            if (!act) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
+            memset(act, 0xff, nbq);
+            for (size_t b = 1; b <= nb; ++b)
+                for (size_t q = nq; q < 8 * nbq; ++q) act[b * nbq + q / 8] |= (uint8_t)(1u << (q % 8));
+            for (int d = 0; d < D; ++d) ctx[d].act_all = act;
         }
     }
 
@@ -949,7 +965,7 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
         }
         for (int d = 0; d < D; ++d) {
             if (ctx[d].rc && !rc) rc = hrt_fail(ctx[d].rc, "device %d: %s", ctx[d].device, ctx[d].err);
-            for (size_t b = 0; b <= nb; ++b) st.live[b] += ctx[d].st.live[b];
+            for (size_t b = 0; b <= nb && b < 34; ++b) st.live[b] += ctx[d].st.live[b];
             st.records += ctx[d].st.records;
             st.records_unblocked += ctx[d].st.records_unblocked;
             st.tests += ctx[d].st.tests;
@@ -967,6 +983,25 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
     }
     st.num_devices = D;
     st.num_batches = G;
+    if (scat_rays && !rc) {
+        /* :469-471, then per bounce and TX the reference's copy of its bit string FROM BYTE 0 (Q12: np / 8 + 1
+         * bytes -- TX 0's bits and the first few of TX 1, which at the time of TX 0's copy are still the
+         * previous bounce's), at stride nb */
+        const size_t nbq = nq / 8 + 1, nbytes = np / 8 + 1;
+        const uint8_t *act = ctx[0].act_all;
+        memcpy(scat_rays->rays_active, act, nbq);
+        for (size_t b = 0; b < nb; ++b)
+            for (size_t tx = 0; tx < ntx; ++tx) {
+                uint8_t *dst = scat_rays->rays_active + (tx * nb + (b + 1)) * nbytes;
+                const uint8_t *cur = act + (b + 1) * nbq, *prev = act + b * nbq;
+                memcpy(dst, cur, nbytes);
+                if (tx == 0 && ntx > 1)
+                    for (size_t bitp = np; bitp < 8 * nbytes; ++bitp) {
+                        const uint8_t m = (uint8_t)(1u << (bitp % 8));
+                        dst[bitp / 8] = (uint8_t)((dst[bitp / 8] & ~m) | (prev[bitp / 8] & m));
+                    }
+            }
+    }
 
 done:
     for (int d = 0; d < D; ++d) {
@@ -979,6 +1014,7 @@ done:
      * some devices without work, but their problems exist) */
     for (int d = (D_created > D ? D_created : D) - 1; d >= 0; --d) hrt_problem_destroy(ctx[d].prob);
     hrt_pool_end(pool_taken);
+    free(ctx[0].act_all);
     free(ctx);
     st.t_total_s = hrt_now_s() - t_begin;
     if (!rc && stats) *stats = st;

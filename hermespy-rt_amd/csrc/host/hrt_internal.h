@@ -116,8 +116,8 @@ typedef struct {
     float *rec2[HRT_REC_FIELDS];   /* second staging set: the copy of the next (bounce, rx) block */
     uint64_t *mask2;              /* overlaps the dense scatter of the current one */
     void *copy_stream, *copy_stream2;   /* two streams: two DMA engines (one engine moves ~28 GB/s) */
-    Ray *cur_rays;          /* RaysInfo emulation: state of every ray */
-    uint8_t *active, *next_active;
+    Ray *cur_rays;          /* RaysInfo emulation: state of every ray of the current batch, [ntx][n_loc] */
+    uint8_t *active, *next_active;   /* (unused since the snapshots are per batch; kept for the pool's layout) */
     float *dirs_batch;      /* gathered launch directions of one batch */
     uint64_t *run_start;    /* per bounce: runs of equal TX in the hit list */
     uint32_t *run_tx;
@@ -134,6 +134,8 @@ typedef struct {
     ChannelInfo *los, *scat;
     RaysInfo *los_rays, *scat_rays;
     uint32_t G;                 /* batches = round-robin shards of the launch set */
+    uint8_t *act_all;           /* RaysInfo: [nb + 1][nq / 8 + 1] active bits of every ray before bounce 0 .. after the
+                                 * last one, shared by the workers (each sets the bits of its own paths) */
     int host_launch, scatter_threads, use_pool;
     size_t amp_stride;          /* floats between consecutive amplitude entries: 1 (the reference's planes) or
                                  * 2 (re/im interleaved: hrt_compute_paths_interleaved) */

@@ -130,7 +130,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     const double t_begin = hrt_now_s();
     if (!scene || !out) return hrt_fail(HRT_E_INVALID, "hrt_compute_paths_list: NULL argument");
     if (np == 0 || nb == 0) return hrt_fail(HRT_E_INVALID, "num_rays and num_bounces must be > 0");
-    if (nb > 32) return hrt_fail(HRT_E_INVALID, "num_bounces > 32 is not supported");
+    if (nb > 65535) return hrt_fail(HRT_E_INVALID, "num_bounces > 65535 is not supported");
     memset(out, 0, sizeof *out);
 
     const int device = (int)pl_env_u64("HRT_DEVICE", 0);
@@ -241,7 +241,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         {
             hrt_stats bs;
             hrt_work_from_counts(prob, &s, h_counts, &bs);
-            for (size_t b = 0; b <= nb; ++b) st.live[b] += bs.live[b];
+            for (size_t b = 0; b <= nb && b < 34; ++b) st.live[b] += bs.live[b];
             st.records += bs.records;
             st.tests += bs.tests - (g ? (uint64_t)nrx * ntx * prob->num_tri : 0);
         }

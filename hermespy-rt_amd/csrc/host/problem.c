@@ -708,8 +708,8 @@ static int shard_check(const hrt_shard *s)
                         s ? s->count : 0, s ? (unsigned long long)s->num_paths : 0ull);
     if (shard_chunk(s) % 64u)
         return hrt_fail(HRT_E_INVALID, "shard chunk %u is not a multiple of 64", shard_chunk(s));
-    if (s->num_bounces == 0 || s->num_bounces > 32)
-        return hrt_fail(HRT_E_INVALID, "num_bounces must be in 1..32");
+    if (s->num_bounces == 0 || s->num_bounces > 65535u)   /* (the reference's loop has no cap: src/compute_paths.c:591) */
+        return hrt_fail(HRT_E_INVALID, "num_bounces must be in 1..65535");
     return HRT_OK;
 }
 
@@ -985,7 +985,7 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
     uint64_t off = 0;
     /* counts[nb + 2], then (from byte 256) one work-unit counter per launch for the trace kernel's
      * dynamic unit distribution on big tables; zeroed together at the start of every trace */
-    L->off_counts = off; off += HRT_CNT_BYTES;
+    L->off_counts = off; off += HRT_CNT_BYTES(s->num_bounces);
     /* survivor counts per super-chunk (HRT_SUPER_CHUNKS chunks of 256 entries) and bounce: directly behind
      * the counts, zeroed with them at the start of every trace */
     L->num_super = cap / HRT_BLOCK / HRT_SUPER_CHUNKS + 1;
@@ -1031,7 +1031,8 @@ struct hrt_timer {
 
 int hrt_timer_create(uint32_t num_bounces, hrt_timer **out)
 {
-    if (!out || num_bounces == 0 || num_bounces > 32) return hrt_fail(HRT_E_INVALID, "hrt_timer_create: bad argument");
+    /* (per-kernel times are recorded for up to 32 bounces: hrt_kernel_times has 33 slots; traces of more bounces run untimed) */
+    if (!out || num_bounces == 0 || num_bounces > 32) return hrt_fail(HRT_E_INVALID, "hrt_timer_create: num_bounces must be in 1..32");
     hrt_timer *t = (hrt_timer *)calloc(1, sizeof *t);
     if (!t) return hrt_fail(HRT_E_NOMEM, "out of host memory");
     t->num_bounces = num_bounces;
@@ -1168,6 +1169,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.num_super = (uint32_t)L.num_super;
     K.off_res = L.off_res;
     K.off_lb = L.off_lb;
+    K.cnt_stride = (uint32_t)HRT_CNT_STRIDE(s->num_bounces);
     K.lb_stride = (uint32_t)L.lb_stride;
     K.off_wide_q = L.off_wide_q; K.off_wide_key = L.off_wide_key; K.wide_cap = (uint32_t)L.wide_cap;
     K.wide_inv = p->d_inv;
@@ -1321,12 +1323,15 @@ void hrt_work_from_counts(const hrt_problem *p, const hrt_shard *s, const uint32
 {
     memset(st, 0, sizeof *st);
     const uint64_t nb = s->num_bounces, T = p->num_tri, nrx = p->num_rx;
-    st->live[0] = (uint64_t)p->num_tx * hrt_shard_num_local(s);
+    /* (hrt_stats.live has 34 slots: the first 33 launches and their hits; the totals cover every launch) */
+    const uint64_t n0 = (uint64_t)p->num_tx * hrt_shard_num_local(s);
+    st->live[0] = n0;
     for (uint64_t b = 1; b <= nb && b < 34; ++b) st->live[b] = counts[b];
     uint64_t tests = (uint64_t)p->num_rx * p->num_tx * T;
     for (uint64_t b = 0; b < nb; ++b) {
-        tests += T * (st->live[b] + nrx * st->live[b + 1]);
-        st->records += nrx * st->live[b + 1];
+        const uint64_t in = b == 0 ? n0 : counts[b], hits = counts[b + 1];
+        tests += T * (in + nrx * hits);
+        st->records += nrx * hits;
     }
     st->tests = tests;
     st->device = p->device;

@@ -1858,7 +1858,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
     // trace can cost a hundred times another (a wave whose rays scattered is walked ray by ray):
     // there the workgroups pull units from a counter (one returning atomic per unit: ~1 us against
     // units of tens of us; on small tables the static deal is cheaper).
-    uint32_t *unit_ctr = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + HRT_CNT_UNITS) + b;
+    uint32_t *unit_ctr = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + P.cnt_stride) + b;
     for (uint32_t unit = blockIdx.x;; unit += gridDim.x) {
         if constexpr (kPull) {
             if (tid == 0) l_wcnt[0] = atomicAdd(unit_ctr, 1u);
@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         WideQ wq;
         if constexpr (VARIANT == 9) {
             if (P.wide_cap != 0u) {
-                wq.cnt = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + HRT_CNT_WIDE) + b;
+                wq.cnt = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + 2u * P.cnt_stride) + b;
                 wq.q = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_q);
                 wq.keys = reinterpret_cast<unsigned long long *>(P.ws + P.off_wide_key);
                 wq.cap = P.wide_cap;
@@ -2110,7 +2110,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_WIDE_WAVES) void hrt_wide_kernel(con
 {
     __shared__ float4 l_rows[HRT_BLOCK / 64u][kCandBuf * 4u];
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    const uint32_t nq = min(reinterpret_cast<const uint32_t *>(P.ws + P.off_counts + HRT_CNT_WIDE)[b], P.wide_cap);
+    const uint32_t nq = min(reinterpret_cast<const uint32_t *>(P.ws + P.off_counts + 2u * P.cnt_stride)[b], P.wide_cap);
     if (nq == 0u) return;
     const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
     const uint32_t T = P.num_tri;
@@ -2262,7 +2262,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_WIDE_WAVES) void hrt_wide_kernel(con
 __global__ __launch_bounds__(HRT_BLOCK) void hrt_wide_finish_kernel(const hrt_kparams P, const uint32_t b)
 {
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    const uint32_t nq = min(reinterpret_cast<const uint32_t *>(P.ws + P.off_counts + HRT_CNT_WIDE)[b], P.wide_cap);
+    const uint32_t nq = min(reinterpret_cast<const uint32_t *>(P.ws + P.off_counts + 2u * P.cnt_stride)[b], P.wide_cap);
     const uint32_t n_in = (b == 0) ? P.n0 : counts[b];
     const uint32_t T = P.num_tri;
     const uint32_t cap4 = (uint32_t)P.cap * 4u;
@@ -3346,13 +3346,13 @@ __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_kernel(const hrt_kparams P)
 // table is cut into kLosSlices x 4 wave-slices per pair; only the SMALLEST accepted distance matters (blocked
 // iff it is <= 1, quirk Q6), so the waves merge the complement of its bit pattern with an atomic maximum into
 // a zeroed word, and the wave that counts in last writes the pair's record.  Words: the free tail of the
-// counter block (off_counts + HRT_CNT_LOS: {max of ~distance bits, waves done} per pair, up to 32 pairs).
+// counter block (off_counts + 3 cnt_stride: {max of ~distance bits, waves done} per pair, up to 32 pairs).
 constexpr uint32_t kLosSlices = 64u;
 __global__ __launch_bounds__(HRT_BLOCK) void hrt_los_big_kernel(const hrt_kparams P)
 {
     const float4 *tri = reinterpret_cast<const float4 *>(P.tri);
     float *out = reinterpret_cast<float *>(P.ws + P.off_los);
-    uint32_t *words = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + HRT_CNT_LOS);
+    uint32_t *words = reinterpret_cast<uint32_t *>(P.ws + P.off_counts + 3u * P.cnt_stride);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t off = blockIdx.x / kLosSlices, slice = blockIdx.x - off * kLosSlices;
     const uint32_t ws_id = slice * (HRT_BLOCK / 64u) + (threadIdx.x >> 6), n_ws = kLosSlices * (HRT_BLOCK / 64u);
@@ -3949,6 +3949,77 @@ static void launch_fused_t(const hrt_kparams *P, uint32_t bounce, size_t lds, hi
     }
 }
 
+// ===================================================================================
+// Export of a rank's compact result as ONE contiguous run of 32-bit words (csrc/host/gather.c; layout in
+// include/hrt_device.h): the only exchange step of the sharded path is the gather of these runs to one rank.
+// ===================================================================================
+struct ExportSeg { unsigned long long src_off; unsigned long long dst_word; unsigned long long n_words; };
+
+// segment-wise copy workspace -> export: blockIdx.y = segment, blockIdx.x strides over its words
+__global__ __launch_bounds__(256) void hrt_export_copy_kernel(const uint8_t *ws, const ExportSeg *segs, uint32_t *out)
+{
+    const ExportSeg g = segs[blockIdx.y];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ws + g.src_off);
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256u + threadIdx.x; k < g.n_words; k += (unsigned long long)gridDim.x * 256u)
+        out[g.dst_word + k] = src[k];
+}
+
+// per (bounce, rx) -- blockIdx.x -- the exclusive prefix of the popcounts of its "unblocked" mask words
+// (prefix[(b nrx + rx) cap/64 + w]) and their total (totals[b nrx + rx]); one workgroup of 1024 per pair
+__global__ __launch_bounds__(1024) void hrt_export_prefix_kernel(const uint8_t *ws, unsigned long long off_counts,
+                                                                 unsigned long long off_masks, unsigned long long cap,
+                                                                 uint32_t num_rx, uint32_t *prefix, uint32_t *totals)
+{
+    __shared__ uint32_t part[16];
+    __shared__ uint32_t base_s;
+    const uint32_t pair = blockIdx.x, b = pair / num_rx, tid = threadIdx.x;
+    const uint32_t H = reinterpret_cast<const uint32_t *>(ws + off_counts)[b + 1];
+    const uint32_t nw = (H + 63u) / 64u;
+    const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(ws + off_masks) + (unsigned long long)pair * (cap / 64u);
+    uint32_t *pw = prefix + (unsigned long long)pair * (cap / 64u);
+    if (tid == 0) base_s = 0u;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < nw; w0 += 1024u) {
+        const uint32_t w = w0 + tid;
+        unsigned long long m = w < nw ? mw[w] : 0ull;
+        if (w + 1u == nw && (H & 63u)) m &= (1ull << (H & 63u)) - 1ull;   // (bits past the list's end are not the kernels' to define)
+        const uint32_t c = (uint32_t)__popcll(m);
+        uint32_t all;
+        const uint32_t incl = block_scan_incl<16>(c, part, tid, all);
+        if (w < nw) pw[w] = base_s + incl - c;
+        __syncthreads();
+        if (tid == 0) base_s += all;
+        __syncthreads();
+    }
+    if (tid == 0) totals[pair] = base_s;
+}
+
+// HRT_EXPORT_UNBLOCKED: per (bounce, rx) -- blockIdx.y -- the unblocked records, compacted in hit order:
+// [U] hit indices, then HRT_REC_FIELDS x [U] values, at dst_word[pair] of the export
+__global__ __launch_bounds__(256) void hrt_export_compact_kernel(const uint8_t *ws, unsigned long long off_counts,
+                                                                 unsigned long long off_masks, unsigned long long off_recs,
+                                                                 unsigned long long rec_block_bytes, unsigned long long cap,
+                                                                 uint32_t num_rx, const uint32_t *prefix, const uint32_t *totals,
+                                                                 const unsigned long long *dst_word, uint32_t *out)
+{
+    const uint32_t pair = blockIdx.y, b = pair / num_rx, rx = pair - b * num_rx;
+    const uint32_t H = reinterpret_cast<const uint32_t *>(ws + off_counts)[b + 1];
+    const uint32_t U = totals[pair];
+    const unsigned long long *mw = reinterpret_cast<const unsigned long long *>(ws + off_masks) + (unsigned long long)pair * (cap / 64u);
+    const uint32_t *pw = prefix + (unsigned long long)pair * (cap / 64u);
+    const uint32_t *rec = reinterpret_cast<const uint32_t *>(ws + off_recs + (unsigned long long)b * rec_block_bytes +
+                                                             (unsigned long long)rx * 9u * cap * 4u);
+    uint32_t *dst = out + dst_word[pair];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < H; i += gridDim.x * 256u) {
+        const unsigned long long m = mw[i >> 6];
+        if (!((m >> (i & 63u)) & 1ull)) continue;
+        const uint32_t pos = pw[i >> 6] + (uint32_t)__popcll(m & ((1ull << (i & 63u)) - 1ull));
+        dst[pos] = i;
+#pragma unroll
+        for (uint32_t k = 0; k < 9u; ++k) dst[(unsigned long long)(1u + k) * U + pos] = rec[(unsigned long long)k * cap + i];
+    }
+}
+
 thread_local char g_err[256];
 
 }  // namespace
@@ -4287,6 +4358,40 @@ int hrt_hip_patch_build(const float *d_tri, uint32_t num_tri, const float *d_pde
                        (hipStream_t)stream, d_tri, num_tri, d_pdef, d_patch_tri, num_patch, d_apex, num_rx, hball,
                        ro_rx, ro_img, d_masks);
     return (int)hipGetLastError();
+}
+
+int hrt_hip_export_copy(const void *d_ws, const void *d_segs, uint32_t num_segs, uint64_t max_words, void *d_out, void *stream)
+{
+    if (num_segs == 0) return 0;
+    uint64_t bx = (max_words + 255u) / 256u;
+    if (bx > 1024u) bx = 1024u;
+    if (bx == 0) bx = 1;
+    hipLaunchKernelGGL(hrt_export_copy_kernel, dim3((uint32_t)bx, num_segs), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_ws, (const ExportSeg *)d_segs, (uint32_t *)d_out);
+    return (int)hipGetLastError();
+}
+int hrt_hip_export_prefix(const void *d_ws, uint64_t off_counts, uint64_t off_masks, uint64_t cap, uint32_t num_bounces,
+                          uint32_t num_rx, uint32_t *d_prefix, uint32_t *d_totals, void *stream)
+{
+    hipLaunchKernelGGL(hrt_export_prefix_kernel, dim3(num_bounces * num_rx), dim3(1024), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_ws, off_counts, off_masks, cap, num_rx, d_prefix, d_totals);
+    return (int)hipGetLastError();
+}
+int hrt_hip_export_compact(const void *d_ws, uint64_t off_counts, uint64_t off_masks, uint64_t off_recs, uint64_t rec_block_bytes,
+                           uint64_t cap, uint32_t num_bounces, uint32_t num_rx, uint64_t max_hits, const uint32_t *d_prefix,
+                           const uint32_t *d_totals, const uint64_t *d_dst_word, void *d_out, void *stream)
+{
+    uint64_t bx = (max_hits + 255u) / 256u;
+    if (bx > 2048u) bx = 2048u;
+    if (bx == 0) return 0;
+    hipLaunchKernelGGL(hrt_export_compact_kernel, dim3((uint32_t)bx, num_bounces * num_rx), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_ws, off_counts, off_masks, off_recs, rec_block_bytes, cap, num_rx, d_prefix, d_totals,
+                       (const unsigned long long *)d_dst_word, (uint32_t *)d_out);
+    return (int)hipGetLastError();
+}
+int hrt_hip_d2d_async(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 
 int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream)

@@ -184,10 +184,11 @@ typedef struct {
     uint32_t los_blocks;  /* fused launch 0: the last los_blocks workgroups of the grid do the LoS pass (0: own kernel) */
     uint32_t phase_bounce;   /* -DHRT_PHASE_STATS builds: the launch whose workgroups record their time stamps */
     uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
+    uint32_t cnt_stride;  /* HRT_CNT_STRIDE(num_bounces): bytes between the parts of the counter block */
     uint32_t records_done; /* set by the shade shim: hrt_records_kernel wrote this launch's records (patch tables) */
     /* queue of the packets that are too wide to cull (big tables, hrt_wide_kernel): wide_cap entries of
      * 8 bytes at off_wide_q, 64 keys of 8 bytes per entry at off_wide_key; the per-launch entry counts are
-     * the u32 at off_counts + HRT_CNT_WIDE + 4 b (zeroed with the counts).  wide_cap 0: no queue */
+     * the u32 at off_counts + 2 cnt_stride + 4 b (zeroed with the counts).  wide_cap 0: no queue */
     uint64_t off_wide_q, off_wide_key;
     uint32_t wide_cap;
     float wide_cos;          /* fine walk: packets whose cone is wider than this cosine go to the wide kernels */
@@ -196,12 +197,12 @@ typedef struct {
                               * waves do not wait for each other), 0 = one per chunk; set by the launch shims */
 } hrt_kparams;
 
-/* the counter block at off_counts (HRT_CNT_BYTES, zeroed at the start of every trace): counts[nb + 2] |
- * one work-unit counter per launch (trees) | one wide-queue entry count per launch | LoS words */
-#define HRT_CNT_UNITS 256u
-#define HRT_CNT_WIDE 512u
-#define HRT_CNT_LOS 768u       /* big-table LoS pass: {max of ~distance bits, waves done} per (rx, tx) pair, up to 32 pairs */
-#define HRT_CNT_BYTES 1024u
+/* the counter block at off_counts (zeroed at the start of every trace), four parts of cnt_stride bytes
+ * (hrt_cnt_stride(num_bounces): 256 up to 62 bounces): counts[nb + 2] | one work-unit counter per launch
+ * (trees) | one wide-queue entry count per launch | LoS words {max of ~distance bits, waves done} per
+ * (rx, tx) pair, up to 32 pairs (256 bytes) */
+#define HRT_CNT_STRIDE(nb) ((((uint64_t)(nb) + 2u) * 4u + 255u) & ~255ull)
+#define HRT_CNT_BYTES(nb) (3u * HRT_CNT_STRIDE(nb) + 256u)
 #define HRT_WIDE_SLICE 1024u  /* table rows of one (packet, slice) item of hrt_wide_kernel: 64 fine spheres */
 
 /* hrt_kparams.fuse */
@@ -243,6 +244,13 @@ int hrt_hip_patch_build(const float *d_tri, uint32_t num_tri, const float *d_pde
                         float ro_rx, float ro_img, unsigned long long *d_masks, void *stream);
 uint64_t hrt_hip_sort_temp_bytes(uint64_t cap);
 int hrt_hip_sort_hits(const hrt_kparams *P, uint32_t bounce, void *stream);
+int hrt_hip_export_copy(const void *d_ws, const void *d_segs, uint32_t num_segs, uint64_t max_words, void *d_out, void *stream);
+int hrt_hip_export_prefix(const void *d_ws, uint64_t off_counts, uint64_t off_masks, uint64_t cap, uint32_t num_bounces,
+                          uint32_t num_rx, uint32_t *d_prefix, uint32_t *d_totals, void *stream);
+int hrt_hip_export_compact(const void *d_ws, uint64_t off_counts, uint64_t off_masks, uint64_t off_recs, uint64_t rec_block_bytes,
+                           uint64_t cap, uint32_t num_bounces, uint32_t num_rx, uint64_t max_hits, const uint32_t *d_prefix,
+                           const uint32_t *d_totals, const uint64_t *d_dst_word, void *d_out, void *stream);
+int hrt_hip_d2d_async(void *dst, const void *src, uint64_t bytes, void *stream);
 int hrt_hip_launch_fs0(const float *d_dirs, uint64_t n, const float *tx_vel3, float mult, float *d_out, void *stream);
 int hrt_hip_launch_order(const uint32_t *d_seg_start, const uint32_t *d_seg_band, uint32_t num_seg,
                          uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,

@@ -23,6 +23,10 @@ EXPORTED = (
     "hrt_timer_read", "hrt_device_count", "hrt_device_malloc", "hrt_device_free",
     "hrt_device_upload", "hrt_device_download", "hrt_device_sync", "hrt_device_mem_info",
     "hrt_selftest_math", "hrt_debug_kernel_stats", "hrt_scene_import_sionna",
+    "hrt_export_meta_words", "hrt_export_words", "hrt_export_locate", "hrt_gather_create", "hrt_gather_destroy",
+    "hrt_gather_meta_words", "hrt_gather_meta_device", "hrt_gather_prepare", "hrt_gather_set_meta", "hrt_gather_meta",
+    "hrt_gather_pack", "hrt_gather_recv_buffer", "hrt_gather_export", "hrt_gather_received", "hrt_rccl_unique_id",
+    "hrt_rccl_comm_create", "hrt_rccl_comm_destroy", "hrt_gather_rccl", "hrt_stats_size", "hrt_layout_size",
 )
 
 HIT_FIELDS = ("ray", "tri", "theta", "fs0", "ox", "oy", "oz", "dx", "dy", "dz",
@@ -58,6 +62,17 @@ class Stats(C.Structure):
                 ("t_total_s", C.c_double), ("device", C.c_int), ("num_devices", C.c_int),
                 ("num_batches", C.c_uint32), ("dev_id", C.c_int * 16), ("dev_batches", C.c_uint32 * 16),
                 ("dev_t_device_s", C.c_double * 16), ("dev_t_readback_s", C.c_double * 16)]
+
+
+class ExportPart(C.Structure):   # hrt_export_part
+    _fields_ = [(k, C.c_uint64) for k in ("hits", "unblocked", "records", "off_hit", "off_index", "off_rec", "off_mask")]
+
+
+class RcclId(C.Structure):       # ncclUniqueId
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+EXPORT_FULL, EXPORT_UNBLOCKED = 0, 1
 
 
 class HrtError(RuntimeError):
@@ -153,6 +168,39 @@ def load():
     L.hrt_debug_kernel_stats.restype = C.c_int
     L.hrt_scene_import_sionna.argtypes = [C.c_char_p, C.POINTER(abi.Scene)]
     L.hrt_scene_import_sionna.restype = C.c_int
+    # packed export and gather (include/hrt_device.h)
+    u32p = C.POINTER(u32)
+    L.hrt_export_meta_words.argtypes = [u32, u32]
+    L.hrt_export_meta_words.restype = u32
+    L.hrt_export_words.argtypes = [u32p, u32, u32, u32]
+    L.hrt_export_words.restype = u64
+    L.hrt_export_locate.argtypes = [u32p, u32, u32, u32, u32, u32, C.POINTER(ExportPart)]
+    L.hrt_gather_create.argtypes = [vp, C.POINTER(Shard), C.c_int, u32, C.POINTER(vp)]
+    L.hrt_gather_destroy.argtypes = [vp]
+    L.hrt_gather_destroy.restype = None
+    L.hrt_gather_meta_words.argtypes = [vp]
+    L.hrt_gather_meta_words.restype = u32
+    L.hrt_gather_meta_device.argtypes = [vp]
+    L.hrt_gather_meta_device.restype = vp
+    L.hrt_gather_prepare.argtypes = [vp, vp, vp]
+    L.hrt_gather_set_meta.argtypes = [vp, u32, u32p]
+    L.hrt_gather_meta.argtypes = [vp, u32]
+    L.hrt_gather_meta.restype = u32p
+    L.hrt_gather_pack.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
+    L.hrt_gather_recv_buffer.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+    L.hrt_gather_export.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+    L.hrt_gather_received.argtypes = [vp, u32]
+    L.hrt_gather_received.restype = vp
+    L.hrt_rccl_unique_id.argtypes = [C.POINTER(RcclId)]
+    L.hrt_rccl_comm_create.argtypes = [C.POINTER(RcclId), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.hrt_rccl_comm_destroy.argtypes = [vp]
+    L.hrt_gather_rccl.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.hrt_stats_size.restype = u64
+    L.hrt_layout_size.restype = u64
+    # the library writes hrt_stats / hrt_layout in full: a mirror of another size would be overrun
+    if int(L.hrt_stats_size()) != C.sizeof(Stats) or int(L.hrt_layout_size()) != C.sizeof(Layout):
+        raise HrtError("lib.py's mirrors of hrt_stats / hrt_layout (%d / %d bytes) do not match the library's (%d / %d)"
+                       % (C.sizeof(Stats), C.sizeof(Layout), int(L.hrt_stats_size()), int(L.hrt_layout_size())))
     _lib = L
     return L
 

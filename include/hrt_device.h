@@ -224,6 +224,62 @@ int hrt_timer_read(hrt_timer *t, hrt_kernel_times *out);
 void hrt_work_from_counts(const hrt_problem *p, const hrt_shard *s, const uint32_t *counts,
                           hrt_stats *out);
 
+/* ---- packed export and gather: the exchange step of the sharded path (one process per GPU) ----
+ * Every rank packs its compact result into ONE run of 32-bit words in HBM (floats bit-cast); the runs are
+ * gathered to one rank.  A rank's META block (hrt_export_meta_words(nb, nrx) u32) holds what sizes the run:
+ *     meta[0 .. nb + 1]                 the counts block of the trace (meta[b + 1] = H_b, the hits of bounce b)
+ *     meta[nb + 2 + b * nrx + rx]       U_(b, rx): the unblocked records of (bounce b, rx)
+ * Layout of the run, bounce after bounce (H = H_b):
+ *     hit rows   [4][H]                 HRT_HIT_RAY, _TRI, _THETA, _FS0
+ *     then per rx -- HRT_EXPORT_FULL:        records [HRT_REC_FIELDS][H], mask [2 * ceil(H / 64)] ("unblocked" bits)
+ *                 -- HRT_EXPORT_UNBLOCKED:   index [U] (hit i of each kept record), records [HRT_REC_FIELDS][U]
+ *                    (blocked records are all zero: 14 % of C3's; they need not travel)
+ * hermespy-rt_amd/sharding.py is the torch.distributed binding of the same layout. */
+#define HRT_EXPORT_FULL 0u
+#define HRT_EXPORT_UNBLOCKED 1u
+typedef struct {
+    uint64_t hits, unblocked, records;      /* H_b, U_(b, rx), records in the run (H or U) */
+    uint64_t off_hit;                       /* word offsets into the run: hit rows [4][hits] */
+    uint64_t off_index;                     /* HRT_EXPORT_UNBLOCKED: [records] hit indices */
+    uint64_t off_rec;                       /* [HRT_REC_FIELDS][records] */
+    uint64_t off_mask;                      /* HRT_EXPORT_FULL: [2 * ceil(hits / 64)] */
+} hrt_export_part;
+uint32_t hrt_export_meta_words(uint32_t num_bounces, uint32_t num_rx);
+uint64_t hrt_export_words(const uint32_t *meta, uint32_t num_bounces, uint32_t num_rx, uint32_t flags);
+int hrt_export_locate(const uint32_t *meta, uint32_t num_bounces, uint32_t num_rx, uint32_t flags, uint32_t bounce,
+                      uint32_t rx, hrt_export_part *out);
+
+/* The gather of one shard's rank (s->rank of s->count) to `root`; buffers are kept between steps.
+ * With a transport of the caller's own (sharding.py: torch.distributed):
+ *     hrt_gather_prepare      meta block of the finished trace in d_workspace, on the device (hrt_gather_meta_device)
+ *     (exchange the meta blocks)   hrt_gather_set_meta for every rank whose block is known here
+ *     hrt_gather_pack         this rank's run;   hrt_gather_recv_buffer: where the root receives rank r's
+ * or, over RCCL (librccl is bound at run time; `comm` is the caller's ncclComm_t, e.g. from
+ * hrt_rccl_comm_create): hrt_gather_rccl does all of it -- ncclAllGather of the meta blocks, one group of
+ * ncclSend / ncclRecv -- and returns when the root holds every run (hrt_gather_export; the other ranks hold the
+ * meta blocks). */
+typedef struct hrt_gather hrt_gather;
+int hrt_gather_create(const hrt_problem *p, const hrt_shard *s, int root, uint32_t flags, hrt_gather **out);
+void hrt_gather_destroy(hrt_gather *g);
+uint32_t hrt_gather_meta_words(const hrt_gather *g);
+const uint32_t *hrt_gather_meta_device(const hrt_gather *g);
+int hrt_gather_prepare(hrt_gather *g, const void *d_workspace, void *stream);
+int hrt_gather_set_meta(hrt_gather *g, uint32_t rank, const uint32_t *host_meta);
+const uint32_t *hrt_gather_meta(const hrt_gather *g, uint32_t rank);   /* host; NULL if not known */
+int hrt_gather_pack(hrt_gather *g, const void *d_workspace, void *stream, const void **d_run, uint64_t *words);
+int hrt_gather_recv_buffer(hrt_gather *g, uint32_t rank, void **d_buf, uint64_t *words);
+int hrt_gather_export(const hrt_gather *g, uint32_t rank, const void **d_run, uint64_t *words);
+const void *hrt_gather_received(const hrt_gather *g, uint32_t rank);
+typedef struct { char internal[128]; } hrt_rccl_id;   /* ncclUniqueId */
+int hrt_rccl_unique_id(hrt_rccl_id *out);
+int hrt_rccl_comm_create(const hrt_rccl_id *id, int world, int rank, int device, void **comm);
+int hrt_rccl_comm_destroy(void *comm);
+int hrt_gather_rccl(hrt_gather *g, void *comm, const void *d_workspace, void *stream, int self_loop);
+
+/* sizes of the structs this build writes in full (a binding compares them with its own mirror) */
+uint64_t hrt_stats_size(void);
+uint64_t hrt_layout_size(void);
+
 /* ---- thin helpers over the HIP runtime for C callers without one ---- */
 int hrt_device_count(int *out);
 int hrt_device_malloc(int device, void **out, uint64_t bytes);

@@ -1,7 +1,8 @@
 """Edge sizes the bundled configurations do not reach: 1 / 7 / 9 / 64 / 65 / 257 rays (less than a
 byte of the active mask, less and one more than a wavefront, one more than a workgroup), a scene
 of ONE triangle, a mesh with ZERO triangles next to a real one, a scene no ray can hit (every
-list empty after launch 0), 32 bounces (the library's maximum).
+list empty after launch 0), 32 bounces and 40 bounces (the reference's loop has no cap, src/compute_paths.c:591;
+the library's per-launch tables are sized by the bounce count, only hrt_stats.live keeps its 34 slots).
 CPU part: oracle against the LIVE reference.  GPU part: product against the oracle."""
 import os
 
@@ -43,11 +44,13 @@ def _cases(tmp):
     out["empty_mesh"] = G.cfg(hole, [[1, 1, 1.0]], [[-1, 0.5, 2.0], [2, -1, 3.0]], 2000, 4)
     out["unreachable"] = G.cfg(far, [[3, 0, 0]], [[0, 0, 0]], 1500, 3)
     out["box_32_bounces"] = K.cfg("box.hrt", [[2, 1, 1.5]], [[0, 0, 2.5]], 3.0, 300, 32)
+    out["box_40_bounces"] = K.cfg("box.hrt", [[2, 1, 1.5]], [[0, 0, 2.5]], 3.0, 300, 40)
+    out["box_70_bounces_2tx"] = K.cfg("box.hrt", [[2, 1, 1.5]], [[0, 0, 2.5], [1, -1, 1.0]], 3.0, 130, 70)
     return out
 
 
 NAMES = ["box_1_rays", "box_7_rays", "box_9_rays", "box_64_rays", "box_65_rays", "box_257_rays",
-         "one_triangle", "empty_mesh", "unreachable", "box_32_bounces"]
+         "one_triangle", "empty_mesh", "unreachable", "box_32_bounces", "box_40_bounces", "box_70_bounces_2tx"]
 
 
 @pytest.mark.parametrize("name", NAMES)

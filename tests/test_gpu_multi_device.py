@@ -22,8 +22,10 @@ from oracle import oracle
 from tests import configs as K
 from tests.parity import compare_dense
 L = lib.load()
+# (with RaysInfo too: every batch writes the snapshots of its own paths, on whatever device it ran; odd ray
+# counts with two TXs put the Q12 bit quirk on a byte that two batches share)
 for c, rays in ((K.small(K.C3, 70000), False), (K.small(K.C4_DOPPLER, 30001), False), (K.small(K.C5, 9000), False),
-                (K.small(K.C3_DOPPLER, 20000), True)):
+                (K.small(K.C3_DOPPLER, 20000), True), (K.small(K.C4_DOPPLER, 20483), True), (K.small(K.C5, 8195), True)):
     st = lib.Stats()
     got = abi.run_compute_paths(L, *K.args(c), with_rays=rays, stats=st)
     ref = oracle.compute_paths(*K.args(c))
@@ -32,9 +34,10 @@ for c, rays in ((K.small(K.C3, 70000), False), (K.small(K.C4_DOPPLER, 30001), Fa
             ref[k] = got[k]
     s = compare_dense(got, ref)
     assert all(v == 0 for v in s.values()), s
-    want = 1 if rays else min(%(want)d, (c["num_paths"] + 4095) // 4096)   # a batch is at least one 4096-path granule
+    want = min(%(want)d, (c["num_paths"] + 4095) // 4096)   # a batch is at least one 4096-path granule
     assert st.num_devices == want, (st.num_devices, want, st.num_batches)
-    assert st.num_batches %% st.num_devices == 0
+    # (batches are a multiple of the devices unless the launch set has too few 4096-path granules for that)
+    assert st.num_batches %% st.num_devices == 0 or st.num_batches == (c["num_paths"] + 4095) // 4096
     # per-device phase times and batch counts (what shows the balance on a node with several GPUs)
     nd = st.num_devices
     assert sum(int(st.dev_batches[d]) for d in range(nd)) == st.num_batches
@@ -113,12 +116,14 @@ def test_several_batches_on_one_device(product_lib, monkeypatch):
     from . import configs as K
     from .parity import compare_dense
     monkeypatch.setenv("HRT_WORKSPACE_BYTES", str(40 << 20))
-    for c in (K.small(K.C3, 150000), K.small(K.C4_DOPPLER, 60001)):
+    for c, rays in ((K.small(K.C3, 150000), False), (K.small(K.C4_DOPPLER, 60001), False), (K.small(K.C3_DOPPLER, 150000), True),
+                    (K.small(K.C4_DOPPLER, 60001), True)):
         st = lib.Stats()
-        got = abi.run_compute_paths(product_lib, *K.args(c), with_rays=False, stats=st)
+        got = abi.run_compute_paths(product_lib, *K.args(c), with_rays=rays, stats=st)
         ref = oracle.compute_paths(*K.args(c))
         for k in ("los_rays", "los_active", "scat_rays", "scat_active"):
-            ref[k] = got[k]
+            if not rays:
+                ref[k] = got[k]
         s = compare_dense(got, ref)
         assert all(v == 0 for v in s.values()), s
         assert st.num_batches > 1 and st.num_devices == 1, (st.num_batches, st.num_devices)

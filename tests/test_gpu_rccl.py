@@ -59,7 +59,50 @@ def _worker(port, q):
             w.wait()
         torch.cuda.synchronize()
         ok &= bool(torch.equal(src, dst))
+        # ---- the C entry (include/hrt_device.h: hrt_gather_rccl): what a C / C++ consumer with one process per
+        # GPU calls -- its own communicator from hrt_rccl_unique_id / hrt_rccl_comm_create, ncclAllGather of the
+        # meta blocks, one group of ncclSend / ncclRecv (world 1: the root sends its export to itself) ----
+        import ctypes as C
+        from hermespy_rt_amd import lib
+        L = lib.load()
+        uid = lib.RcclId()
+        lib.check(L.hrt_rccl_unique_id(C.byref(uid)), "hrt_rccl_unique_id")
+        comm = C.c_void_p()
+        lib.check(L.hrt_rccl_comm_create(C.byref(uid), 1, 0, 0, C.byref(comm)), "hrt_rccl_comm_create")
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for flags in (lib.EXPORT_FULL, lib.EXPORT_UNBLOCKED):
+            gh = C.c_void_p()
+            lib.check(L.hrt_gather_create(tr.problem, C.byref(tr.shard), 0, flags, C.byref(gh)), "hrt_gather_create")
+            for _ in range(2):
+                lib.check(L.hrt_gather_rccl(gh, comm, C.c_void_p(tr.ws.data_ptr()), st, 1), "hrt_gather_rccl")
+            ptr, words = C.c_void_p(), C.c_uint64()
+            lib.check(L.hrt_gather_export(gh, 0, C.byref(ptr), C.byref(words)), "hrt_gather_export")
+            n = int(words.value)
+            mine = torch.as_tensor(sharding._DevPtr(ptr.value, n), device=dev)
+            got = torch.as_tensor(sharding._DevPtr(L.hrt_gather_received(gh, 0), n), device=dev)
+            ok &= bool(torch.equal(mine, got)) and n > 0
+            mw = int(L.hrt_gather_meta_words(gh))
+            meta = np.ctypeslib.as_array(L.hrt_gather_meta(gh, 0), shape=(mw,)).copy()
+            ok &= [int(x) for x in meta[1:tr.nb + 1]] == [int(x) for x in counts[1:tr.nb + 1]]
+            if flags == lib.EXPORT_FULL:
+                ok &= bool(torch.equal(got, exports[0]))          # the torch binding packs the same run
+            else:
+                ub = meta[tr.nb + 2:]
+                views = sharding.unpack_export(got, meta[:tr.nb + 2], tr.nb, tr.nrx, ub, sharding.UNBLOCKED)
+                for b, v in enumerate(views):
+                    h = int(counts[b + 1])
+                    rec = tr.rec_block(b)
+                    bits = tr.mask_block(b).cpu().numpy().view(np.uint64)
+                    for rx in range(tr.nrx):
+                        m = ((bits[rx][np.arange(h) // 64] >> (np.arange(h) % 64).astype(np.uint64)) & np.uint64(1)).astype(bool)
+                        idx = torch.from_numpy(np.nonzero(m)[0].astype(np.int64)).to(dev)
+                        ok &= int(ub[b * tr.nrx + rx]) == int(m.sum())
+                        ok &= bool(torch.equal(v["index"][rx].to(torch.int64), idx))
+                        ok &= bool(torch.equal(v["rec"][rx], rec[rx][:, idx]))
+            L.hrt_gather_destroy(gh)
+        lib.check(L.hrt_rccl_comm_destroy(comm), "hrt_rccl_comm_destroy")
         q.put(bool(ok))
+        g.close()
         tr.close()
     finally:
         dist.destroy_process_group()

@@ -33,8 +33,10 @@ def _worker(rank, world, port, q):
         g = sharding.RecordGather(tr, dst=0)
         for _ in range(2):                       # buffers are reused across steps
             exports = g.run()
+        g2 = sharding.RecordGather(tr, dst=0, unblocked_only=True)   # (checked below)
+        exports2 = g2.run()
         if rank != 0:
-            assert exports is None
+            assert exports is None and exports2 is None
             return
         ref = oracle.compute_paths(*K.args(c))
         nrx, ntx, nb, npth = tr.nrx, tr.ntx, tr.nb, tr.num_paths
@@ -69,6 +71,38 @@ def _worker(rank, world, port, q):
                     ok &= bool(same.all())
         ok &= np.array_equal(seen, written(ref["scat"]["a_te_re"]))   # every record of the reference, once
         q.put(bool(ok))
+        # ---- the same gather with the unblocked records only (HRT_EXPORT_UNBLOCKED: compacted on the device by
+        # the C entry): every non-zero record of the reference, once, and nothing else ----
+        exports = exports2
+        ok = True
+        seen = np.zeros((nrx, ntx, nb, npth), bool)
+        for r in range(world):
+            cnt, ub_cnt = g2.counts_all[r], g2.meta_all[r][nb + 2:]
+            n_loc = int(tr.L.hrt_shard_num_local(__import__("ctypes").byref(
+                __import__("hermespy_rt_amd.lib", fromlist=["Shard"]).Shard(npth, r, world, 0, nb))))
+            full = sharding.export_words(g.counts_all[r], nb, nrx)
+            ok &= exports[r].numel() < full                          # (C3: ~14 % of the records are blocked)
+            for b, v in enumerate(sharding.unpack_export(exports[r].cpu(), cnt, nb, nrx, ub_cnt, sharding.UNBLOCKED)):
+                h = int(cnt[b + 1])
+                if not h:
+                    continue
+                ray = v["hit"][0].numpy().astype(np.int64) & 0xFFFFFFFF
+                tx = ray // n_loc
+                i = ray - tx * n_loc
+                p = ((i // ch) * world + r) * ch + i % ch
+                for rx in range(nrx):
+                    idx = v["index"][rx].numpy().astype(np.int64)
+                    rec = v["rec"][rx].numpy().view(np.float32)     # [9, U]
+                    ok &= bool((np.diff(idx) > 0).all())            # hit order
+                    seen[rx, tx[idx], b, p[idx]] = True
+                    for k, name in enumerate(("a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau")):
+                        ok &= np.array_equal(rec[k].view(np.uint32), ref["scat"][name][rx, tx[idx], b, p[idx]].view(np.uint32))
+                    d = ref["scat"]["directions_rx"][rx, tx[idx], b, p[idx]]
+                    ok &= np.array_equal(rec[5:8].T.view(np.uint32), d.view(np.uint32))
+        ok &= np.array_equal(seen, written(ref["scat"]["directions_rx"][..., 0]))   # dir_rx is written for unblocked records only
+        q.put(bool(ok))
+        g2.close()
+        g.close()
         tr.close()
     finally:
         dist.destroy_process_group()
@@ -94,4 +128,5 @@ def test_real_tracer_shards_gathered_over_gloo(world):
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    assert q.get() is True
+    assert q.get() is True      # full export
+    assert q.get() is True      # unblocked records only
