@@ -480,12 +480,18 @@ static int run_batch(dev_ctx *c, uint32_t g)
         c->t_launch += hrt_now_s() - t0;
         t0 = hrt_now_s();
     }
-    if ((rc = hrt_trace(prob, &s, (const float *)w->d_dirs, (const uint32_t *)w->d_order, w->d_ws, L.total_bytes, NULL, NULL))) goto done;
-    if ((rc = hrt_device_sync(w->device, NULL))) goto done;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = hrt_trace(prob, &s, (const float *)w->d_dirs, (const uint32_t *)w->d_order, w->d_ws, L.total_bytes, NULL, NULL))) goto done;
+        if ((rc = hrt_device_sync(w->device, NULL))) goto done;
+        DL(w->h_counts, L.off_counts, (nb + 2) * 4);
+        /* a fused launch gave up waiting (the GPU is shared with other fused kernels: hrt_kernels.hip,
+         * lb_exclusive): the step is void -- once more, two kernels per launch, and so from now on */
+        if (!(w->h_counts[nb + 1] & HRT_ERR_FUSE_TIMEOUT) || attempt) break;
+        hrt_fuse_disable();
+    }
     c->t_dev += hrt_now_s() - t0;
 
     t0 = hrt_now_s();
-    DL(w->h_counts, L.off_counts, (nb + 2) * 4);
     if (w->h_counts[nb + 1] != 0) {
         rc = hrt_fail(HRT_E_HIP, "device reported internal error flags %u", w->h_counts[nb + 1]);
         goto done;

@@ -73,6 +73,7 @@ struct hrt_problem {
     void *d_rxt;                 /* per-RX direction tables (device blob), or NULL */
     hrt_krxt krxt;
     uint64_t rxt_entries;        /* total list entries over all (rx, cell) */
+    uint32_t *h_fuse_flag, *d_fuse_flag;   /* pinned word a fused launch sets when it gives up (hrt_kparams.host_flag) */
     void *aux_stream;            /* second stream of a trace: the records kernels run beside the bounce kernels */
     void *aux_ev[2];             /* fork (live list complete) / join (records done): ordering-only events */
     void *d_patch;               /* patch tables (device blob), or NULL */
@@ -97,6 +98,10 @@ int hrt_fail_hip(int hip_err, const char *what);
     } while (0)
 
 double hrt_now_s(void);
+/* fused launches off for the rest of the process (a fused launch timed out: the GPU is shared with other fused
+ * kernels); hrt_trace looks at it, and at the problem's pinned flag word, before every trace */
+void hrt_fuse_disable(void);
+int hrt_fuse_disabled(void);
 
 /* ---- buffers of one device worker of the drop-in calls (compute_paths.c), pooled between calls ---- */
 typedef struct {

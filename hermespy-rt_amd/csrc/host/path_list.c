@@ -227,13 +227,18 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             t_dirs += hrt_now_s() - t0;
             t0 = hrt_now_s();
         }
-        if ((rc = hrt_trace(prob, &s, (const float *)d_dirs, (const uint32_t *)d_order, d_ws,
-                            L.total_bytes, NULL, NULL))) goto done;
-        if ((rc = hrt_device_sync(device, NULL))) goto done;
+        for (int attempt = 0;; ++attempt) {
+            if ((rc = hrt_trace(prob, &s, (const float *)d_dirs, (const uint32_t *)d_order, d_ws,
+                                L.total_bytes, NULL, NULL))) goto done;
+            if ((rc = hrt_device_sync(device, NULL))) goto done;
+            DLP(h_counts, L.off_counts, (nb + 2) * 4);
+            /* (a fused launch timed out on a shared GPU: the step is void, once more unfused -- compute_paths.c) */
+            if (!(h_counts[nb + 1] & HRT_ERR_FUSE_TIMEOUT) || attempt) break;
+            hrt_fuse_disable();
+        }
         t_dev += hrt_now_s() - t0;
 
         t0 = hrt_now_s();
-        DLP(h_counts, L.off_counts, (nb + 2) * 4);
         if (h_counts[nb + 1] != 0) {
             rc = hrt_fail(HRT_E_HIP, "device reported internal error flags %u", h_counts[nb + 1]);
             goto done;

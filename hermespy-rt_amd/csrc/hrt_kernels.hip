@@ -57,6 +57,7 @@ constexpr float kEps = 1.1920928955078125e-07f;             // FLT_EPSILON
 constexpr float kOnePlusEps = 1.00000011920928955078125f;   // next float after 1
 constexpr float kPi = 3.14159265358979323846f;              // src/compute_paths.c:18 (float)
 constexpr float kC = 299792458.0f;                          // src/compute_paths.c:19
+constexpr uint32_t kErrFuseTimeout = HRT_ERR_FUSE_TIMEOUT;   // bit of the trace's error word (counts[nb + 1]): see lb_exclusive
 
 struct F3 { float x, y, z; };
 
@@ -1796,6 +1797,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
     const uint32_t tid = threadIdx.x;
     const bool first = (b == 0);
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = first ? P.n0 : counts[b];
     const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
     // unit types of this launch: the shadow rays (b >= 1), one type per RX (k = rx) -- with patch tables
@@ -2335,6 +2337,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     const bool first = (b == 0);
     const bool do_trace = (b < P.num_bounces);
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = first ? P.n0 : counts[b];
     if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;
 
@@ -2620,6 +2623,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_RECORDS_WAVES) void hrt_records_kern
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = counts[b];
     const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
     if (blockIdx.x >= n_chunks) return;
@@ -2779,8 +2783,25 @@ __device__ __forceinline__ LbWords lb_words(const hrt_kparams &P, uint32_t b)
 // Exclusive prefix of `chunk` (survivors of all earlier chunks); c = the chunk's own count (already
 // published in its word).  Called by all 64 lanes of ONE wave (uniform control flow); the result is
 // wave-uniform.
-__device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chunk, uint32_t c, uint32_t lane)
+// Bounded: the chunks in front are waited for at most HRT_LB_MAX_POLLS polls (about 10 ms; the wait is
+// microseconds when the kernel owns the GPU).  A chunk only ever waits for lower-numbered chunks, and those have
+// been dispatched -- per XCD: the XCDs dispatch their shares of a grid independently, so a resident workgroup can
+// spin on one that still waits for a slot on another XCD.  Alone on the GPU that slot comes; when several fused
+// kernels (four processes sharing one GPU) fill each other's slots with spinning workgroups it does not until a
+// time slice ends: C4 took 5.8 s per step instead of 0.2 ms.  On a timeout the launch is declared VOID: the
+// error word of the trace (counts[nb + 1]) gets kErrFuseTimeout, every spinning workgroup that sees it leaves,
+// every later kernel of the trace returns at once, and the host -- which sees the bit in the counts it reads
+// anyway, and a flag word in pinned memory without any synchronisation -- runs the step again as two kernels
+// per launch and keeps fusion off from then on.  (Tickets drawn at workgroup start make the order exact, but a
+// returning atomic on one address per workgroup cost 10 % of C4's step and 30 % of C2's: profiles/HISTORY.md r4.)
+constexpr uint32_t kLbAbort = 0xffffffffu;
+#ifndef HRT_LB_MAX_POLLS
+#define HRT_LB_MAX_POLLS 8000u   /* ~10 ms of polling */
+#endif
+__device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chunk, uint32_t c, uint32_t lane,
+                                                 uint32_t *err_word, uint32_t *host_flag)
 {
+    uint32_t polls = 0u;
     const uint32_t g = chunk >> 6, sg = chunk >> 12;
     const bool want_c = (g << 6) + lane < chunk, want_g = (sg << 6) + lane < g;
     const bool want_s0 = lane < sg, want_s1 = lane + 64u < sg;
@@ -2807,6 +2828,14 @@ __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chun
             s_owed = false;
         }
         if (ok_c && ok_g && ok_s) return sum_c + sum_g + wave_sum_u32((s0 & ~kLbDone) + (s1 & ~kLbDone));
+        if (lb_load(err_word) & kErrFuseTimeout) return kLbAbort;        // somebody gave up: the launch is void
+        if (++polls > HRT_LB_MAX_POLLS) {
+            if (lane == 0) {
+                atomicOr(err_word, kErrFuseTimeout);
+                if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return kLbAbort;
+        }
         __builtin_amdgcn_s_sleep(4);
     }
 }
@@ -2935,6 +2964,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
         return;
     }
     const uint32_t n_in = FIRST ? P.n0 : counts[b];
+    if (!FIRST && (counts[P.num_bounces + 1] & kErrFuseTimeout)) return;   // an earlier fused launch of this trace timed out
     // A SHORT list is bound by the latency of one workgroup, not by throughput: then a workgroup takes
     // one packet per wave (macro-chunk = 256 entries), which spreads the list over K times as many CUs
     // (the grid covers ceil(cap / (256 K)) macro-chunks, so this needs n_in <= grid * 256).
@@ -3220,13 +3250,14 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
         const bool need_prefix = c_total != 0u || (chunk & 63u) == 63u || chunk + 1u == n_chunks;
         if (need_prefix) {   // (uniform over the workgroup)
             if (tid < 64u) {   // wave 0
-                const uint32_t excl = lb_exclusive(W, chunk, c_total, lane);
+                const uint32_t excl = lb_exclusive(W, chunk, c_total, lane, &counts[P.num_bounces + 1], P.host_flag);
                 if (lane == 0) {
                     L.wcnt[8] = excl;
-                    if (chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length
+                    if (excl != kLbAbort && chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length
                 }
             }
             __syncthreads();
+            if (L.wcnt[8] == kLbAbort) return;   // (uniform) the launch is void: see lb_exclusive
         }
         HRT_PHASE(12);
         uint32_t pos = L.wcnt[8];
@@ -4035,6 +4066,12 @@ int hrt_hip_malloc(void **p, uint64_t bytes) { return (int)hipMalloc(p, bytes ? 
 int hrt_hip_free(void *p) { return (int)hipFree(p); }
 int hrt_hip_host_malloc(void **p, uint64_t bytes) { return (int)hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault); }
 int hrt_hip_host_free(void *p) { return p ? (int)hipHostFree(p) : 0; }
+int hrt_hip_host_malloc_mapped(void **host, void **dev, uint64_t bytes)   /* page-locked and visible to the device */
+{
+    int rc = (int)hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocMapped);
+    if (!rc) rc = (int)hipHostGetDevicePointer(dev, *host, 0);
+    return rc;
+}
 int hrt_hip_h2d(void *dst, const void *src, uint64_t bytes)
 {
     return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);

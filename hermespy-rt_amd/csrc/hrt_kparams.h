@@ -10,6 +10,8 @@ extern "C" {
 #endif
 
 #define HRT_NO_HIT 0xFFFFFFFFu
+#define HRT_ERR_FUSE_TIMEOUT 0x100u   /* error word of a trace (counts[nb + 1]): a fused launch timed out waiting for its
+                                       * prefix (GPU shared with other fused kernels); the step is void, redo it unfused */
 #define HRT_NUM_MATERIALS 17
 #define HRT_TRI_FLOATS 20  /* v1(3) e1(3) e2(3) n(3) E_d c_uv c_w (culling tolerances) |e1| |e2| |e2-e1| |e1xe2| mesh_id(u32) */
 #define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */
@@ -185,6 +187,8 @@ typedef struct {
     uint32_t phase_bounce;   /* -DHRT_PHASE_STATS builds: the launch whose workgroups record their time stamps */
     uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
     uint32_t cnt_stride;  /* HRT_CNT_STRIDE(num_bounces): bytes between the parts of the counter block */
+    uint32_t *host_flag;  /* a word in page-locked host memory (device address): set to 1 when a fused launch gives up
+                           * waiting (HRT_ERR_FUSE_TIMEOUT) -- the host sees it without synchronising; or NULL */
     uint32_t records_done; /* set by the shade shim: hrt_records_kernel wrote this launch's records (patch tables) */
     /* queue of the packets that are too wide to cull (big tables, hrt_wide_kernel): wide_cap entries of
      * 8 bytes at off_wide_q, 64 keys of 8 bytes per entry at off_wide_key; the per-launch entry counts are
@@ -217,6 +221,7 @@ int hrt_hip_malloc(void **p, uint64_t bytes);
 int hrt_hip_free(void *p);
 int hrt_hip_host_malloc(void **p, uint64_t bytes);   /* page-locked host memory */
 int hrt_hip_host_free(void *p);
+int hrt_hip_host_malloc_mapped(void **host, void **dev, uint64_t bytes);
 int hrt_hip_h2d(void *dst, const void *src, uint64_t bytes);
 int hrt_hip_d2h(void *dst, const void *src, uint64_t bytes);
 int hrt_hip_memset_async(void *dst, int value, uint64_t bytes, void *stream);
