@@ -385,7 +385,7 @@ def main():
                     shade_kernel_ms=[float(x) for x in sm.mean(axis=0)],
                     kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
                     compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
-                    trace_variant=os.environ.get("HRT_TRACE_VARIANT", "auto (flat packet culling; trees on big sparse tables)"),
+                    trace_variant=os.environ.get("HRT_TUNE", "auto (patch tables on 65-256 triangles; flat packet culling; trees on big sparse tables)"),
                     valu=valu,
                     note=("a fused launch reports its one kernel under trace_kernel_ms (shade_kernel_ms = 0); "
                           "frac is the north-star's HBM figure (algorithmic bytes / kernel time / 8 TB/s); "

@@ -212,7 +212,7 @@ static int cmp_float(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
-int hrt_accel_build(hrt_accel *a, const float *rows)
+int hrt_accel_build(hrt_accel *a, const float *rows, const hrt_tune *tune)
 {
     const uint32_t T = a->num_tri;
     const uint32_t nl = (T + 63u) / 64u;
@@ -252,8 +252,8 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
      * HRT_FINE_MIN_TRI triangles that are not "big" (HRT_ACCEL_FINE_MIN=n replaces the threshold;
      * HRT_ACCEL_FINE=0 brings the 64-row leaf walk back). */
     int want_fine = T > HRT_FINE_MIN_TRI;
-    { const char *mv = getenv("HRT_ACCEL_FINE_MIN"); if (mv && *mv) want_fine = (unsigned long long)T > strtoull(mv, NULL, 10); }
-    { const char *fv = getenv("HRT_ACCEL_FINE"); if (fv && *fv && atoi(fv) == 0) want_fine = 0; }
+    if (tune->accel_fine_min != UINT64_MAX) want_fine = (unsigned long long)T > tune->accel_fine_min;
+    if (tune->accel_fine == 0) want_fine = 0;
     if (want_fine) {
         const uint32_t nfn = (T + HRT_FINE_ROWS - 1u) / HRT_FINE_ROWS;
         a->fine = (float *)calloc((size_t)nfn * HRT_NODE_FLOATS, sizeof(float));
@@ -284,13 +284,12 @@ int hrt_accel_build(hrt_accel *a, const float *rows)
          * most leaves at a distance): tables of more than HRT_ACCEL_BIG triangles whose median leaf
          * radius is below HRT_ACCEL_SPARSE of the scene's.  In a dense scene (a room full of clutter,
          * every leaf near every ray) the per-triangle culling of the flat walk is the better tool.
-         * Environment: HRT_ACCEL_BIG=n replaces the triangle threshold (0: always) and drops the
-         * sparseness condition; HRT_ACCEL_SPARSE=x replaces the ratio. */
-        const char *v = getenv("HRT_ACCEL_BIG"), *sp = getenv("HRT_ACCEL_SPARSE");
-        const unsigned long long thr = (v && *v) ? strtoull(v, NULL, 10) : HRT_ACCEL_BIG;
-        a->big = (unsigned long long)T > thr;
-        if (a->big && !(v && *v)) {
-            const double ratio = (sp && *sp) ? atof(sp) : HRT_ACCEL_SPARSE;
+         * HRT_TUNE: accel_big=n replaces the triangle threshold (0: always) and drops the
+         * sparseness condition; accel_sparse=x replaces the ratio. */
+        const int forced = tune->accel_big != HRT_ACCEL_BIG;
+        a->big = (unsigned long long)T > tune->accel_big;
+        if (a->big && !forced) {
+            const double ratio = tune->accel_sparse;
             float *rad = (float *)malloc((size_t)nl * sizeof(float));
             double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
             uint32_t n = 0;

@@ -574,7 +574,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
             }
         }
     }
-    const int can_pre = (ntx == 1) && !scat_rays && !env_int("HRT_NO_BOUNCE_PREFETCH", 0);
+    const int can_pre = (ntx == 1) && !scat_rays && !prob->tune.no_bounce_prefetch;
     /* slim records (default; HRT_FULL_RECORDS=1 copies all nine fields): see scatter_ctx */
     const int slim = !env_int("HRT_FULL_RECORDS", 0);
     static const int hs_field[4] = {HRT_HIT_OX, HRT_HIT_OY, HRT_HIT_OZ, HRT_HIT_TAU};
@@ -697,7 +697,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
                         for (int k = 0; k < 4; ++k) sc.hs[k] = w->hs[k];
                         sc.rxp[0] = rx_pos[rx].x; sc.rxp[1] = rx_pos[rx].y; sc.rxp[2] = rx_pos[rx].z;
                     }
-                    if (!env_int("HRT_DEBUG_NO_SCATTER", 0))   /* timing experiments: copies only */
+                    if (!prob->tune.no_scatter)   /* (HRT_TUNE no_scatter: timing experiments, copies only) */
                         hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
                     for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st->records_unblocked += sc.unblocked[t];
                 }

@@ -30,6 +30,23 @@ typedef struct {
 } hrt_eta;
 void hrt_material_eta(uint32_t material_index, float f_ghz, hrt_eta *out);
 
+/* developer / test switches (tune.c: HRT_TUNE="key=value,..."), read once per problem */
+typedef struct {
+    hrt_ktune k;                 /* the part the launch shims see (hrt_kparams.tune) */
+    double wide_cos;             /* 0: by table size */
+    int64_t wide_cap;            /* -1: auto */
+    int sort_rays, sort_fine, sort_dir_res;   /* sort_rays -1: by table size */
+    uint64_t rxt_min_rays;       /* UINT64_MAX: by table size */
+    uint32_t rxt_max_tri;
+    int no_rxt, no_txt, no_reorder, no_patch;
+    double patch_size, accel_sparse;
+    uint64_t accel_big, accel_fine_min;   /* accel_fine_min UINT64_MAX: HRT_FINE_MIN_TRI */
+    int accel_fine;              /* -1: auto, 0: never */
+    int no_bounce_prefetch, no_scatter;
+} hrt_tune;
+void hrt_tune_defaults(hrt_tune *t);
+int hrt_tune_load(hrt_tune *t);
+
 /* acceleration structure over the triangle table (accel.c; device side in hrt_kernels.hip) */
 typedef struct hrt_accel {
     uint32_t num_tri, num_leaf;
@@ -51,11 +68,12 @@ typedef struct hrt_accel {
     float *fine;                 /* [num_fine][HRT_NODE_FLOATS]: sphere + Lambda of HRT_FINE_ROWS rows, or NULL */
 } hrt_accel;
 int hrt_accel_order(hrt_accel *a, const float *rows_ref_order, uint32_t T, int reorder);
-int hrt_accel_build(hrt_accel *a, const float *rows_table_order);
+int hrt_accel_build(hrt_accel *a, const float *rows_table_order, const hrt_tune *tune);
 void hrt_accel_free(hrt_accel *a);
 
 struct hrt_problem {
     int device;
+    hrt_tune tune;
     uint32_t num_tri, num_mesh, num_rx, num_tx;
     float f_ghz, fsl_mult, dop_mult;
     /* host copies */

@@ -257,7 +257,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             if ((rc = pl_reserve(out, &cap_out, out->num + recs))) goto done;
         }
         int pre = 0, flip = 0;   /* staging set of a block: (rx + flip) & 1 */
-        const int can_pre = !(int)pl_env_u64("HRT_NO_BOUNCE_PREFETCH", 0);
+        const int can_pre = !prob->tune.no_bounce_prefetch;
         for (size_t b = 0; b < nb; ++b) {
             const uint64_t H = h_counts[b + 1];
             if (!H) continue;

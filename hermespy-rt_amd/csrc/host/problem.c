@@ -147,17 +147,16 @@ static int rxt_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
 {
     /* apexes: the RXs (shadow rays converge on them), then the TXs (the launch set leaves them) */
     const uint32_t T = p->num_tri, n_rx = p->num_rx;
-    const char *off_env = getenv("HRT_NO_RXT"), *notx_env = getenv("HRT_NO_TXT");
-    uint32_t max_tri = HRT_RXT_MAX_TRI;
-    { const char *mv = getenv("HRT_RXT_MAX_TRI"); if (mv && *mv) max_tri = (uint32_t)atol(mv); if (max_tri > 65535u) max_tri = 65535u; }
+    uint32_t max_tri = p->tune.rxt_max_tri;
+    if (max_tri > 65535u) max_tri = 65535u;
     /* Up to 64 triangles the whole table is ONE culling round, a list cannot be cheaper: there the
      * tables are one 64-bit candidate MASK per (apex, cell), built for the cell alone, looked up per
      * ray (closest_hit_masked) -- RXs and TXs alike, up to 256 apexes (110 KB each). */
     const int per_ray = T <= 64;
-    if (T > max_tri || (off_env && *off_env && *off_env != '0')) return HRT_OK;
+    if (T > max_tri || p->tune.no_rxt) return HRT_OK;
     if (per_ray ? (n_rx + p->num_tx > 256) : (n_rx > 64)) return HRT_OK;
     const uint32_t n_txt = per_ray ? p->num_tx
-                                   : ((n_rx + p->num_tx <= 64 && !(notx_env && *notx_env && *notx_env != '0')) ? p->num_tx : 0u);
+                                   : ((n_rx + p->num_tx <= 64 && !p->tune.no_txt) ? p->num_tx : 0u);
     const uint32_t nrx = n_rx + n_txt;
     /* the ball every ray origin lies in: hit points are on triangles (+ 1e-4 along the new direction) */
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -279,17 +278,16 @@ out:
 
 /* ---- patch tables (hrt_kpatch, hrt_kparams.h): the grid of every triangle, the list patch -> triangle,
  * and the device pass that fills the candidate masks.  Tables of 65 .. HRT_PATCH_MAX_TRI triangles. ----
- * Patch edge: HRT_PATCH_SIZE metres (default 0.5: C3 4.5 candidates per shadow ray against 7.4 at 1 m and
+ * Patch edge: 0.5 m (HRT_TUNE patch_size: C3 4.5 candidates per shadow ray against 7.4 at 1 m and
  * 17.7 at 2 m, profiles/study/), enlarged until all tables fit HRT_PATCH_MAX_BYTES (default 1 GiB). */
 static int patch_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
 {
     const uint32_t T = p->num_tri, n_rx = p->num_rx, n_tx = p->num_tx;
-    { const char *v = getenv("HRT_NO_PATCH"); if (v && *v && *v != '0') return HRT_OK; }
+    if (p->tune.no_patch) return HRT_OK;
     /* (up to 64 triangles the fused kernels with their per-cell masks are faster: patch tables + a records
      * kernel measured 0.86 against 0.66 ms on C4, 0.080 / 0.050 on C2, 0.047 / 0.022 on C1) */
     if (T <= 64u || T > HRT_PATCH_MAX_TRI || n_rx + n_tx > 4096u) return HRT_OK;
-    double size = 0.5, max_bytes = 1024.0 * 1024.0 * 1024.0;
-    { const char *v = getenv("HRT_PATCH_SIZE"); if (v && *v && atof(v) > 0.0) size = atof(v); }
+    double size = p->tune.patch_size > 0.0 ? p->tune.patch_size : 0.5, max_bytes = 1024.0 * 1024.0 * 1024.0;
     { const char *v = getenv("HRT_PATCH_MAX_BYTES"); if (v && *v && atof(v) > 0.0) max_bytes = atof(v); }
     if (max_bytes > 3.5e9) max_bytes = 3.5e9;   /* the kernels address the masks with 32-bit byte offsets */
     /* extent of everything a ray origin or an apex can be */
@@ -439,6 +437,10 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
 
     hrt_problem *p = (hrt_problem *)calloc(1, sizeof *p);
     if (!p) return hrt_fail(HRT_E_NOMEM, "out of host memory");
+    {   /* developer / test switches, once per problem (tune.c) */
+        const int rct = hrt_tune_load(&p->tune);
+        if (rct) { free(p); return rct; }
+    }
     p->device = device;
     p->num_tri = (uint32_t)T;
     p->num_mesh = scene->num_meshes;
@@ -514,8 +516,7 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
     /* ---- acceleration structure: Morton order of the rows (the reference's loop order is kept
      * in accel.orig for the tie-break), leaf spheres, guard numbers, inner levels, plane tree ---- */
     {
-        const char *nv = getenv("HRT_NO_REORDER");
-        int rc2 = hrt_accel_order(&p->accel, p->h_tri, (uint32_t)T, !(nv && *nv && *nv != '0'));
+        int rc2 = hrt_accel_order(&p->accel, p->h_tri, (uint32_t)T, !p->tune.no_reorder);
         if (rc2) { hrt_problem_destroy(p); return rc2; }
         float *rows = (float *)malloc((size_t)(T ? T : 1) * HRT_TRI_FLOATS * sizeof(float));
         uint32_t *tm = (uint32_t *)malloc((size_t)(T ? T : 1) * 4), *tf = (uint32_t *)malloc((size_t)(T ? T : 1) * 4);
@@ -532,7 +533,7 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         }
         free(p->h_tri); free(p->h_tri_mesh); free(p->h_tri_face);
         p->h_tri = rows; p->h_tri_mesh = tm; p->h_tri_face = tf;
-        rc2 = hrt_accel_build(&p->accel, p->h_tri);
+        rc2 = hrt_accel_build(&p->accel, p->h_tri, &p->tune);
         if (rc2) { hrt_problem_destroy(p); return rc2; }
     }
 
@@ -617,7 +618,6 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
     ka->leaf = (const float *)(b + offs[i_leaf]);
     ka->num_leaf = A->num_leaf;
     ka->big = A->big ? 1u : 0u;
-    { const char *dv = getenv("HRT_ACCEL_DEBUG"); ka->dbg = (dv && *dv) ? (uint32_t)atoi(dv) : 0u; }
     ka->num_levels = A->num_levels;
     for (uint32_t k = 0; k < A->num_levels; ++k) {
         ka->node_count[k] = A->node_count[k];
@@ -653,11 +653,11 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
             p->scene_lo[k] = isfinite(lo[k]) ? (float)lo[k] : 0.f;
             p->scene_hi[k] = isfinite(hi[k]) ? (float)hi[k] : 1.f;
         }
-        const char *sv = getenv("HRT_SORT_RAYS");
+
         /* default: tables beyond HRT_SORT_MIN_TRI triangles -- there a wave that scattered costs a
          * staged pass over the whole table, and the sort (a few passes over the live list) is cheap
          * against it; on small tables (C3) the sort would cost more than the whole trace */
-        p->sort_rays = (sv && *sv) ? (*sv != '0') : (p->num_tri > HRT_SORT_MIN_TRI);
+        p->sort_rays = p->tune.sort_rays >= 0 ? (p->tune.sort_rays != 0) : (p->num_tri > HRT_SORT_MIN_TRI);
         uint32_t txb = 0;
         while ((1u << txb) < p->num_tx) ++txb;
         if (24u + txb > 32u) p->sort_rays = 0;   /* 15 bits of cell + up to 9 of direction + TX */
@@ -665,7 +665,7 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
     {
         /* (the per-ray masks of tables of <= 64 triangles need no host pass over the lists: ~0.2 ms) */
         uint64_t min_rays = p->num_tri <= 64u ? 1ull << 18 : 1ull << 26;
-        { const char *mv = getenv("HRT_RXT_MIN_RAYS"); if (mv && *mv) min_rays = strtoull(mv, NULL, 10); }
+        if (p->tune.rxt_min_rays != UINT64_MAX) min_rays = p->tune.rxt_min_rays;
         if (rays_hint >= min_rays) {
             int rcx = rxt_build(p, rx_pos, tx_pos);
             if (!rcx) rcx = patch_build(p, rx_pos, tx_pos);
@@ -1017,8 +1017,7 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *L)
          * not fit is walked by the pushing wave itself) */
         const uint64_t traces = (cap / 64) * ((uint64_t)p->num_rx + 1);
         L->wide_cap = traces / 2 < 1024 ? 1024 : traces / 2;
-        const char *wv = getenv("HRT_WIDE_CAP");
-        if (wv && *wv) L->wide_cap = strtoull(wv, NULL, 10);
+        if (p->tune.wide_cap >= 0) L->wide_cap = (uint64_t)p->tune.wide_cap;
         if (L->wide_cap > 0x7fffffffull / 64) L->wide_cap = 0x7fffffffull / 64;
         L->off_wide_q = off;   off += round_up(L->wide_cap * 8 + 8, 256);
         L->off_wide_key = off; off += round_up(L->wide_cap * 64 * 8 + 8, 256);
@@ -1192,10 +1191,8 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     K.lb_stride = (uint32_t)L.lb_stride;
     K.off_wide_q = L.off_wide_q; K.off_wide_key = L.off_wide_key; K.wide_cap = (uint32_t)L.wide_cap;
     K.wide_inv = p->d_inv;
-    {
-        const char *wc = getenv("HRT_WIDE_COS");
-        K.wide_cos = (wc && *wc) ? (float)atof(wc) : (p->num_tri >= HRT_WIDE_COS_BIG_TRI ? HRT_WIDE_COS_BIG : HRT_WIDE_COS);
-    }
+    K.wide_cos = p->tune.wide_cos != 0.0 ? (float)p->tune.wide_cos : (p->num_tri >= HRT_WIDE_COS_BIG_TRI ? HRT_WIDE_COS_BIG : HRT_WIDE_COS);
+    K.tune = p->tune.k;
     K.lb_chunks = (uint32_t)round_up(L.cap / HRT_BLOCK + 1, 64);
     K.fuse = fuse_mode(p);
     if (p->sort_rays) {
@@ -1204,14 +1201,13 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
         K.sort.enabled = 1u;
         {   /* 15 bits of cell, dealt to the axes so that the cells come out about cubic (a bit at a
              * time to the axis whose cells are longest); HRT_SORT_DIR_RES: cells per cube-face edge
-             * of the direction bins (default 2: 24 bins); HRT_SORT_FINE: how many of the 15 cell bits
+             * of the direction bins (default 2: 24 bins); sort_fine: how many of the 15 cell bits
              * sort BEHIND the direction (default 6: key = 512 coarse cells | 24 directions | 64 fine
              * cells -- shadow rays, the majority, only care about the origin, the bounce itself
              * about both; measured on the room of 6 012 triangles: 13.9 / 9.7 / 9.3 / 11.4 ms for
              * 0 / 6 / 9 / 15, on the city of 25 002: 24.4 / 23.0 / 24.7 / 22.4) */
-            const char *dv = getenv("HRT_SORT_DIR_RES"), *fv = getenv("HRT_SORT_FINE");
-            uint32_t res = (dv && *dv) ? (uint32_t)atoi(dv) : 2u;
-            uint32_t nfine = (fv && *fv) ? (uint32_t)atoi(fv) : 6u;
+            uint32_t res = (uint32_t)(p->tune.sort_dir_res > 0 ? p->tune.sort_dir_res : 2);
+            uint32_t nfine = (uint32_t)(p->tune.sort_fine >= 0 ? p->tune.sort_fine : 6);
             if (res < 1u) res = 1u;
             if (res > 8u) res = 8u;
             if (nfine > 15u) nfine = 15u;

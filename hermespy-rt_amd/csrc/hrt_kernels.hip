@@ -261,6 +261,11 @@ __device__ unsigned int g_unit_n;
 // active (callers run in uniform control flow); inputs must not be NaN.  (The leading s_nop 4
 // covers the worst hazard in front of a DPP instruction -- 5 wait states after a VALU write of
 // EXEC -- since the compiler's hazard recogniser does not look inside inline assembly.)
+__device__ __forceinline__ float lane63f(float v, uint32_t l)   // the value of lane l (wave-uniform l), in every lane
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)l));
+}
+constexpr uint32_t kMaxSourceGroups = 6u;   // virtual sources of a wave traced as packets of their own (then: the rest as one)
 __device__ __forceinline__ float lane63(float v)
 {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
@@ -1109,7 +1114,7 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
     // size tried (city, T = 25 002: 192 ms with ranges down to single rays, 62 ms down to 8 lanes,
     // 31 ms with the one pass): a tree walk is a chain of dependent loads, the staged pass streams.
     // HRT_ACCEL_DEBUG bit 3 (8) re-enables the cutting for experiments.
-    const uint32_t min_range = (A.dbg & 8u) ? ((A.dbg & 4u) ? 8u : 1u) : 64u;
+    const uint32_t min_range = 64u;
     unsigned long long unresolved = 0ull;
     uint32_t rs = 0;
     if (lane == 0) rstack[0] = 0u | (64u << 8);
@@ -1214,7 +1219,7 @@ __device__ __forceinline__ Hit closest_hit_big(TriPtr tri, LeafPtr leaf, const h
             }
         }
         // ---- plane tree: level pl_levels-1 = top ... level 0 = cones of the 64-entry leaves ----
-        if (!(A.dbg & 2u)) {
+        {
             const uint32_t L = A.pl_levels - 1u;
             auto visit = [&](uint32_t k, uint32_t base) -> unsigned long long {
                 const uint32_t count = k == 0u ? A.pl_count[0] : (k == 1u ? A.pl_count[1] : A.pl_count[2]);
@@ -1459,7 +1464,7 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
         }
     }
     // ---- plane tree: level pl_levels-1 = top ... level 0 = cones of the 64-entry leaves (as closest_hit_big) ----
-    if (!(A.dbg & 2u)) {   // (HRT_ACCEL_DEBUG bit 1 skips it: UNSOUND, timing experiments only)
+    {
         const uint32_t L = A.pl_levels - 1u;
         auto visit = [&](uint32_t k, uint32_t base) -> unsigned long long {
             const uint32_t count = k == 0u ? A.pl_count[0] : (k == 1u ? A.pl_count[1] : A.pl_count[2]);
@@ -1533,9 +1538,6 @@ __device__ __forceinline__ Hit closest_hit_fine(TriPtr tri, const hrt_kaccel &A,
     return {who, best};
 }
 
-#ifndef HRT_TRACE_VARIANT_DEFAULT
-#define HRT_TRACE_VARIANT_DEFAULT 7   /* auto */
-#endif
 
 // Called by ALL lanes of a wave (uniform control flow); lanes with valid == false carry a dummy
 // ray and their result is meaningless.  VARIANT: 0 plain, 1 staged, 2 / 3 flat packet culling
@@ -1890,9 +1892,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         const bool shadow = kq < sh_units;
         const uint32_t k = shadow ? kq : P.num_rx;   // (without patch tables: the RX of a shadow unit)
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
-        uint32_t tx_lane = 0u, htri = 0u;
-        // (patch tables: shadow rays, and the bounce rays of launch 1 -- first-order images of the TXs)
-        const bool patched = psa && !shadow && b == 1u && P.patch.num_img != 0u;
+        uint32_t tx_lane = 0u;
         if (valid) {
             if (first) {
                 uint32_t ray;
@@ -1904,10 +1904,6 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
                 if (!shadow)
                     d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4),
                          ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
-                if (patched) {
-                    htri = ldu(hit_blk(P, pb), H_TRI * cap4, i4);
-                    if (!shadow && P.num_tx != 1u) tx_lane = min(ldu(hit_blk(P, pb), H_RAY * cap4, i4) / P.num_local, P.num_tx - 1u);
-                }
             }
         }
         F3 apex = {0.f, 0.f, 0.f};
@@ -1931,7 +1927,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         const bool masked = VARIANT == 2 && P.rxt.cell_mask != nullptr && (shadow || first);
         Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
         if constexpr (VARIANT >= 2 && VARIANT != 6)
-            if (!masked && !patched) ball = origin_ball(o, valid);
+            if (!masked && (VARIANT != 2 || shadow || first)) ball = origin_ball(o, valid);
         WideQ wq;
         if constexpr (VARIANT == 9) {
             if (P.wide_cap != 0u) {
@@ -1952,12 +1948,33 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
         Hit h = {HRT_NO_HIT, 1e9f};
         bool done = false;
         if constexpr (VARIANT == 2) {
-            if (patched) {
-                // the apex: the image of the lane's own TX in the plane of the triangle it left
-                const F3 pa = {P.tx_pos[3 * tx_lane], P.tx_pos[3 * tx_lane + 1], P.tx_pos[3 * tx_lane + 2]};
-                PatchRef ref = {false, 0u};
-                if (valid) ref = patch_locate(tri, P.patch, T, htri, o, true, pa, d);
-                h = closest_hit_patch(tri, P.acc.orig, P.patch, ref, P.num_rx + tx_lane, T, o, d, valid, lane, 1);
+            // The primary rays of a later launch, split by VIRTUAL SOURCE.  Rays that took the same sequence of
+            // reflections leave one image of their TX (o - d * path length), and neighbours in launch order that
+            // did so form a narrow packet; a wave that mixes sequences is a wide packet that culls little or
+            // nothing.  Measured on C3 (profiles/study/split_study.py): 1.13 / 1.24 groups per wave at launches 2 /
+            // 3, and the candidates drop from 14.2 / 20.8 per wave to 3.8 / 4.1 -- the mixed waves carried them.
+            // The lanes of one virtual source go through packet culling as ONE packet, group after group; any
+            // partition is sound (each group's packet is tested for itself), this one is just the coherent one.
+            if (!done && !shadow && !first) {
+                const float lp = valid ? ldf(hit_blk(P, b - 1), H_TAU * cap4, i4) * kC : 0.f;
+                const F3 vs = {o.x - d.x * lp, o.y - d.y * lp, o.z - d.z * lp};
+                unsigned long long rem = HRT_BALLOT(valid);
+                uint32_t groups = 0u;
+                while (rem) {
+                    const uint32_t l0 = (uint32_t)__builtin_ctzll(rem);
+                    const F3 v0 = {lane63f(vs.x, l0), lane63f(vs.y, l0), lane63f(vs.z, l0)};
+                    const float tol = 1e-2f + 1e-5f * lane63f(lp, l0);
+                    bool in = ((rem >> lane) & 1ull) != 0ull;
+                    // (the last group takes whatever is left; lane l0 is in its own group whatever its numbers are)
+                    if (++groups < kMaxSourceGroups)
+                        in = in && ((fabsf(vs.x - v0.x) + fabsf(vs.y - v0.y)) + fabsf(vs.z - v0.z) <= tol || lane == l0);
+                    const unsigned long long gm = HRT_BALLOT(in);
+                    const Ball gb = origin_ball(o, in);
+                    const Hit hg = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, o, d, in, lane, gb,
+                                                        false, apex, l_mask, l_wleaf, 1, wq);
+                    if (in) h = hg;
+                    rem &= ~gm;
+                }
                 done = true;
             }
         }
@@ -2126,7 +2143,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_WIDE_WAVES) void hrt_wide_kernel(con
     float4 *cbuf = l_rows[wave];
     const uint64_t n_slices = ((uint64_t)T + HRT_WIDE_SLICE - 1u) / HRT_WIDE_SLICE;
     const uint64_t n_items = n_slices * nq;
-    const bool cull = !(P.acc.dbg & 16u);   // (HRT_ACCEL_DEBUG bit 4: every slice flat, timing experiments)
+    const bool cull = true;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     [[maybe_unused]] const int kind = 1;
     for (uint64_t item = (uint64_t)blockIdx.x * (HRT_BLOCK / 64u) + wave; item < n_items;
@@ -2611,6 +2628,67 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                 stf(hit_out(P, b), H_TAU * cap4, k4, tau);
             }
         }
+    }
+}
+
+// ===================================================================================
+// IMAGE kernel (patch tables): the primary rays of launch 1.  They left a TX and were mirrored once, so every
+// one of them leaves the image of its TX in the plane of the triangle it sits on: the lane locates its patch,
+// checks that its line does pass the image (patch_locate), and the wave walks the union of the lanes'
+// (image apex, patch) masks -- no packet is formed, and a wave that mixes surfaces pays for the union of a few
+// small sets.  Results and survivor counts as hrt_trace_kernel writes them for the shade kernel.
+// LDS: [T x 5 float4 rows][4 u32].
+// ===================================================================================
+__global__ __launch_bounds__(HRT_BLOCK, 8) void hrt_image_kernel(const hrt_kparams P, const uint32_t b)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
+    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
+    const uint32_t n_in = counts[b];
+    const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
+    if (blockIdx.x >= n_chunks) return;
+    const uint32_t T = P.num_tri;
+    const uint32_t cap4 = (uint32_t)P.cap * 4u;
+    float4 *l_tri = lds;
+    uint32_t *l_wcnt = reinterpret_cast<uint32_t *>(lds + HRT_ROW * T);
+    {
+        const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+        for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) l_tri[k] = g_tri[k];
+    }
+    __syncthreads();
+    const float4 *tri = l_tri;
+    const uint32_t pb = b - 1;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t i = chunk * HRT_BLOCK + tid;
+        const uint32_t i4 = i * 4u;
+        const bool valid = i < n_in;
+        F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
+        uint32_t tx = 0u;
+        PatchRef ref = {false, 0u};
+        if (valid) {
+            o = {ldf(hit_blk(P, pb), H_OX * cap4, i4), ldf(hit_blk(P, pb), H_OY * cap4, i4), ldf(hit_blk(P, pb), H_OZ * cap4, i4)};
+            d = {ldf(hit_blk(P, pb), H_DX * cap4, i4), ldf(hit_blk(P, pb), H_DY * cap4, i4), ldf(hit_blk(P, pb), H_DZ * cap4, i4)};
+            const uint32_t htri = ldu(hit_blk(P, pb), H_TRI * cap4, i4);
+            if (P.num_tx != 1u) tx = min(ldu(hit_blk(P, pb), H_RAY * cap4, i4) / P.num_local, P.num_tx - 1u);
+            // the apex: the image of the lane's own TX in the plane of the triangle it left
+            ref = patch_locate(tri, P.patch, T, htri, o, true, {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]}, d);
+        }
+        const Hit h = closest_hit_patch(tri, P.acc.orig, P.patch, ref, P.num_rx + tx, T, o, d, valid, lane, 1);
+        if (valid) {
+            stu(res_blk(P, P.num_rx), 0u, i4, h.tri);
+            stf(res_blk(P, P.num_rx), cap4, i4, h.t);
+        }
+        // survivors of the chunk and of its super-chunk (hrt_trace_kernel's protocol: the shade kernel sums them)
+        const unsigned long long hm = __ballot(valid && h.tri != HRT_NO_HIT);
+        if (lane == 0) l_wcnt[tid >> 6] = (uint32_t)__popcll(hm);
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t c = l_wcnt[0] + l_wcnt[1] + l_wcnt[2] + l_wcnt[3];
+            reinterpret_cast<uint32_t *>(P.ws + P.off_chunk_cnt)[chunk] = c;
+            atomicAdd(reinterpret_cast<uint32_t *>(P.ws + P.off_super_cnt) + (uint64_t)b * P.num_super + (chunk >> HRT_SUPER_SHIFT), c);
+        }
+        __syncthreads();
     }
 }
 
@@ -3932,13 +4010,6 @@ static void launch_trace_t(const hrt_kparams *P, uint32_t bounce, uint32_t block
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (*err != hipSuccess) return;
     }
-    static const bool report = getenv("HRT_DEBUG_OCCUPANCY") != nullptr;
-    if (report && bounce == 1) {   // diagnostic: resident workgroups per CU at this LDS size
-        int nblk = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, hrt_trace_kernel<LDS, V>, HRT_BLOCK, lds);
-        fprintf(stderr, "hrt_trace_kernel: %d workgroups of %u threads per CU at %zu bytes of LDS\n", nblk,
-                HRT_BLOCK, lds);
-    }
     hipLaunchKernelGGL((hrt_trace_kernel<LDS, V>), dim3(blocks), dim3(HRT_BLOCK), lds, st, *P,
                        bounce);
 }
@@ -4119,7 +4190,7 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
 int hrt_hip_launch_los(const hrt_kparams *P, void *stream)
 {
     const uint32_t pairs = P->num_rx * P->num_tx, per_block = HRT_BLOCK / 64u;
-    static const uint64_t big_min = env_u64("HRT_LOS_BIG_MIN_TRI", 16384);
+    const uint64_t big_min = P->tune.los_big_min_tri;
     if (P->num_tri >= big_min && pairs != 0u && pairs <= 32u) {
         hipLaunchKernelGGL(hrt_los_big_kernel, dim3(pairs * kLosSlices), dim3(HRT_BLOCK), 0, (hipStream_t)stream, *P);
         return (int)hipGetLastError();
@@ -4132,8 +4203,8 @@ int hrt_hip_launch_los(const hrt_kparams *P, void *stream)
 // does this problem walk the fine leaves (tables beyond LDS with fine spheres built, no big-table trees)?
 static bool walks_fine(const hrt_kparams *P)
 {
-    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
-    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const int variant = P->tune.variant;
+    const uint64_t lds_max = P->tune.lds_tri_bytes_max;
     const uint64_t T = P->num_tri;
     const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
                                (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
@@ -4146,8 +4217,8 @@ static bool walks_fine(const hrt_kparams *P)
 // `bounce` >= 1 are hrt_records_kernel's (launched by hrt_hip_launch_trace), the shade kernel skips them
 static bool records_in_own_kernel(const hrt_kparams *P, uint32_t bounce)
 {
-    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
-    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const int variant = P->tune.variant;
+    const uint64_t lds_max = P->tune.lds_tri_bytes_max;
     const uint64_t T = P->num_tri;
     const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
                                (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
@@ -4168,19 +4239,19 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
     const uint64_t kinds = (bounce == 0) ? 1u : (bounce < P->num_bounces ? P->num_rx + 1u : P->num_rx);
     uint64_t blocks = ((n_max + HRT_BLOCK - 1) / HRT_BLOCK) * kinds;
-    static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
+    const uint64_t max_grid = P->tune.trace_grid ? P->tune.trace_grid : HRT_TRACE_GRID;
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
     // HRT_TRACE_VARIANT: unset = auto (see below).
     // 6 = trees wherever built, else 4; 4 = packet culling behind the leaf spheres + guard; 2 = flat
     // packet culling; 1 = staged tests over all triangles; 0 = the reference's plain sequence.  All
     // give bit-identical results; the GPU tests run all of them.
-    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
+    const int variant = P->tune.variant;
     const uint64_t T = P->num_tri;
     // staged image: rows + guard pairs (padded to 16 B) + leaf records
     const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
                                (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
-    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const uint64_t lds_max = P->tune.lds_tri_bytes_max;
     const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;   // packet culling: single-block build
     const bool fine_pre = !in_lds && !(P->acc.big && variant >= 4 && variant != 9) && P->acc.fine != nullptr &&
@@ -4201,7 +4272,7 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     if (fine) {
         launch_trace_t<false, 9>(P, bounce, nb, lds, st, &err);
         if (err == hipSuccess && P->wide_cap != 0u) {   // the packets the walk queued as too wide to cull
-            static const uint64_t wide_grid = env_u64("HRT_WIDE_GRID", kWideGrid);
+            const uint64_t wide_grid = P->tune.wide_grid ? P->tune.wide_grid : kWideGrid;
             hipLaunchKernelGGL(hrt_wide_kernel, dim3((uint32_t)wide_grid), dim3(HRT_BLOCK), 0, st, *P, bounce);
             hipLaunchKernelGGL(hrt_wide_finish_kernel, dim3(256), dim3(HRT_BLOCK), 0, st, *P, bounce);
         }
@@ -4215,7 +4286,11 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
                 if (bounce < P->num_bounces) {
                     uint64_t pblocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
                     if (pblocks > max_grid) pblocks = max_grid;
-                    launch_trace_t<true, 2>(P, bounce, (uint32_t)pblocks, lds, st, &err);
+                    if (bounce == 1 && P->patch.num_img != 0u)   // first-order images of the TXs: hrt_image_kernel
+                        hipLaunchKernelGGL(hrt_image_kernel, dim3((uint32_t)pblocks), dim3(HRT_BLOCK),
+                                           (size_t)T * HRT_TRI_FLOATS * 4u + 16u, st, *P, bounce);
+                    else
+                        launch_trace_t<true, 2>(P, bounce, (uint32_t)pblocks, lds, st, &err);
                 }
             } else if (one_block) launch_trace_t<true, 2>(P, bounce, nb, lds, st, &err);
             else launch_trace_t<true, 3>(P, bounce, nb, lds, st, &err);
@@ -4238,7 +4313,7 @@ int hrt_hip_launch_trace(const hrt_kparams *P_in, uint32_t bounce, void *stream)
 int hrt_hip_launch_records(const hrt_kparams *P, uint32_t bounce, void *stream)
 {
     if (!records_in_own_kernel(P, bounce)) return -1;
-    static const uint64_t max_grid = env_u64("HRT_TRACE_GRID", HRT_TRACE_GRID);
+    const uint64_t max_grid = P->tune.trace_grid ? P->tune.trace_grid : HRT_TRACE_GRID;
     const uint64_t T = P->num_tri;
     uint64_t rblocks = (P->cap + HRT_BLOCK - 1) / HRT_BLOCK;
     if (rblocks > 2u * max_grid) rblocks = 2u * max_grid;   // (1 024 .. 4 096 workgroups: 2-5 % slower)
@@ -4259,11 +4334,11 @@ int hrt_hip_launch_shade(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     const hrt_kparams *P = &Pc;
     const uint64_t n_max = (bounce == 0) ? P->n0 : P->cap;
     uint64_t blocks = (n_max + HRT_BLOCK - 1) / HRT_BLOCK;
-    static const uint64_t max_grid = env_u64("HRT_SHADE_GRID", HRT_SHADE_GRID);
+    const uint64_t max_grid = P->tune.shade_grid ? P->tune.shade_grid : HRT_SHADE_GRID;
     if (blocks > max_grid) blocks = max_grid;
     if (blocks == 0) blocks = 1;
     const size_t lds0 = (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)P->num_rx * 16u + 32u;
-    static const uint64_t nlds_off = env_u64("HRT_SHADE_NO_LDS_NORMALS", 0);
+    const uint64_t nlds_off = P->tune.shade_global_normals;
     if (!nlds_off && P->num_tri <= kShadeLdsTri && P->num_mesh <= kShadeLdsMesh)
         hipLaunchKernelGGL(hrt_shade_kernel<true>, dim3((uint32_t)blocks), dim3(HRT_BLOCK),
                            lds0 + ((size_t)P->num_tri + P->num_mesh) * 16u, (hipStream_t)stream, *P, bounce);
@@ -4284,11 +4359,11 @@ int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     else if (Pc.los_blocks) Pc.los_blocks = (Pc.num_rx * Pc.num_tx + HRT_BLOCK / 64u - 1u) / (HRT_BLOCK / 64u);
     const hrt_kparams *P = &Pc;
     if (P->cap / HRT_BLOCK + 1u > P->lb_chunks) return (int)hipErrorInvalidValue;   // (one word per chunk)
-    static const int variant = (int)env_u64("HRT_TRACE_VARIANT", HRT_TRACE_VARIANT_DEFAULT);
+    const int variant = P->tune.variant;
     const uint64_t T = P->num_tri;
     const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
                                (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
-    static const uint64_t lds_max = env_u64("HRT_LDS_TRI_BYTES_MAX", HRT_LDS_TRI_BYTES_MAX);
+    const uint64_t lds_max = P->tune.lds_tri_bytes_max;
     const bool in_lds = T * HRT_TRI_FLOATS * 4u <= lds_max && tri_bytes <= 144u * 1024u;
     const bool one_block = P->num_tri <= kMaskRounds * 64u;
     const bool fine_pre = !in_lds && !(P->acc.big && variant >= 4 && variant != 9) && P->acc.fine != nullptr &&
@@ -4300,7 +4375,7 @@ int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
     hipError_t err = hipSuccess;
     // the same choice of intersection loop as hrt_hip_launch_trace; on tables of a handful of
     // triangles (auto) the staged walk over all of them is cheaper than a culling round
-    static const uint64_t staged_max = env_u64("HRT_FUSE_STAGED_MAX_TRI", 6);
+    const uint64_t staged_max = P->tune.fuse_staged_max_tri;
     const bool trees = P->acc.big && (variant >= 4) && variant != 9;
     const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
     const bool staged = variant == 1 || (variant == 7 && T <= staged_max);

@@ -49,9 +49,6 @@ typedef struct {
     const float *leaf;              /* [num_leaf][HRT_NODE_FLOATS] */
     uint32_t num_leaf;
     uint32_t big;                   /* inner levels + plane tree present */
-    uint32_t dbg;                   /* HRT_ACCEL_DEBUG bits (timing experiments only): 2 skip the plane tree
-                                     * (UNSOUND), 8 cut unusable packets into lane ranges (4: down to 8 lanes),
-                                     * 16 the wide kernel runs every slice flat (no culling) */
     uint32_t num_levels;
     uint32_t node_count[HRT_ACCEL_MAX_LEVELS];
     const float *node[HRT_ACCEL_MAX_LEVELS];
@@ -149,6 +146,15 @@ typedef struct {
     uint64_t off_tmp, tmp_bytes;    /* workspace: digit histograms of the radix sort ([256][tiles] + 256 totals) */
 } hrt_ksort;
 
+/* developer / test switches that reach the launch shims (csrc/host/tune.c: HRT_TUNE, read once per problem) */
+typedef struct {
+    int32_t variant;               /* intersection loop: HRT_TRACE_VARIANT_DEFAULT = auto */
+    uint64_t lds_tri_bytes_max;    /* tables up to this many bytes are staged in LDS */
+    uint32_t trace_grid, shade_grid, wide_grid;
+    uint32_t los_big_min_tri, fuse_staged_max_tri, shade_global_normals;
+} hrt_ktune;
+#define HRT_TRACE_VARIANT_DEFAULT 7
+
 typedef struct {
     /* scene (device pointers) */
     const float *tri;     /* [num_tri][HRT_TRI_FLOATS] in (mesh, face) order */
@@ -159,6 +165,7 @@ typedef struct {
     hrt_krxt rxt;
     hrt_kpatch patch;
     hrt_ksort sort;
+    hrt_ktune tune;
     /* endpoints (device pointers, [n][3]) */
     const float *rx_pos, *tx_pos, *rx_vel, *tx_vel;
     uint32_t num_rx, num_tx;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Time per step of the hot path on generated rooms full of tilted boxes (tests/scenes_gen.py) as a
-function of the triangle count T, for one HRT_TRACE_VARIANT (latched per process):
+function of the triangle count T, for one intersection variant (HRT_TUNE variant=...):
 
-    HRT_TRACE_VARIANT=2 python profiles/accel_scaling.py 24 91 166 500 1000 4000 8333
+    HRT_TUNE=variant=2 python profiles/accel_scaling.py 24 91 166 500 1000 4000 8333
 
 1 M rays, 3 RX, 2 bounces (the workload of DESIGN.md section 9).  HRT_SCALING_SCENE=city: the
 argument is the number of buildings per side of tests/scenes_gen.city (10 n^2 + 2 triangles).  Prints one JSON line per scene."""
@@ -49,7 +49,7 @@ def main():
         los_ms, trace_ms = tr.trace(timed=True)
         c = tr.counts()
         w = tr.work(c)
-        print(json.dumps(dict(variant=os.environ.get("HRT_TRACE_VARIANT", "default"), boxes=nb, T=T,
+        print(json.dumps(dict(variant=os.environ.get("HRT_TUNE", "default"), boxes=nb, T=T,
                               ms_per_step=ms, trace_ms=[round(x, 3) for x in trace_ms],
                               shade_ms=[round(x, 3) for x in tr.last_shade_ms], live=w["live"], tests_per_s=w["tests"] / ms * 1e3,
                               setup_s=t_build)), flush=True)

@@ -42,4 +42,4 @@ for k, name in enumerate(("primary0", "primary", "shadow")):
     row = {c: int(arr[k * 16 + j]) for j, c in enumerate(cols)}
     wt = max(1, row["wave_traces"])
     row["per_trace"] = {c: round(row[c] / wt, 2) for c in cols[1:]}
-    print(json.dumps(dict(T=T, kind=name, variant=os.environ.get("HRT_TRACE_VARIANT", "default"), **row)))
+    print(json.dumps(dict(T=T, kind=name, variant=os.environ.get("HRT_TUNE", "default"), **row)))

@@ -1,5 +1,5 @@
 """Warm drop-in calls (hrt_compute_paths_ex) of the small-table workloads, phase by phase; run with
-HRT_NO_RXT=1 too to see what the per-cell candidate masks cost (setup) and save (device)."""
+HRT_TUNE=no_rxt=1 too to see what the per-cell candidate masks cost (setup) and save (device)."""
 import sys
 sys.path.insert(0, ".")
 from hermespy_rt_amd import abi, lib, workloads as W

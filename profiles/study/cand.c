@@ -382,3 +382,47 @@ void patch_eval(const float *rows, int T, const PatchDef *pd, const float *o, co
     }
     out[0] = nw; out[1] = s1; out[2] = s2; out[3] = s3; out[5] = s5;
 }
+
+/* bounce traces with the wave split into groups of equal `group id` (the reflection sequence of each ray):
+ * per wave, cost model  sum over groups ( overhead + per_cand * candidates(group packet) ), an unusable
+ * group costing per_cand * T.  mode 0: never split; 1: split only waves whose whole packet is wide
+ * (cos < cos_min) or unusable; 2: always split.  out: [0] waves, [1] total cost, [2] groups walked,
+ * [3] candidates walked, [4] unusable (sub)packets */
+void bounce_eval_split(const float *rows, int T, const float *o, const float *d, const int32_t *gid, int n, int mode,
+                       float cos_min, double overhead, double per_cand, double *out)
+{
+    const int nw = (n + 63) / 64;
+    double cost = 0, groups = 0, cands = 0, unus = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : cost, groups, cands, unus)
+    for (int w = 0; w < nw; ++w) {
+        const int i0 = w * 64, cnt = (n - i0 < 64) ? n - i0 : 64;
+        Packet P;
+        packet_of(o + 3 * (size_t)i0, d + 3 * (size_t)i0, cnt, 0, NULL, &P);
+        int split = mode == 2 || (mode == 1 && (!P.usable || P.cosa < cos_min));
+        if (!split) {
+            int pk = T;
+            if (P.usable) { pk = 0; for (int j = 0; j < T; ++j) pk += !packet_culls(&P, rows + (size_t)j * ROWF); } else unus += 1;
+            cost += overhead + per_cand * pk; groups += 1; cands += pk;
+            continue;
+        }
+        int done[64] = {0};
+        for (int l = 0; l < cnt; ++l) {
+            if (done[l]) continue;
+            float go[192], gd[192];
+            int m = 0;
+            for (int k = l; k < cnt; ++k)
+                if (!done[k] && gid[i0 + k] == gid[i0 + l]) {
+                    done[k] = 1;
+                    memcpy(go + 3 * m, o + 3 * (size_t)(i0 + k), 12);
+                    memcpy(gd + 3 * m, d + 3 * (size_t)(i0 + k), 12);
+                    ++m;
+                }
+            Packet G;
+            packet_of(go, gd, m, 0, NULL, &G);
+            int pk = T;
+            if (G.usable) { pk = 0; for (int j = 0; j < T; ++j) pk += !packet_culls(&G, rows + (size_t)j * ROWF); } else unus += 1;
+            cost += overhead + per_cand * pk; groups += 1; cands += pk;
+        }
+    }
+    out[0] = nw; out[1] = cost; out[2] = groups; out[3] = cands; out[4] = unus;
+}

@@ -78,7 +78,9 @@ int main(int argc, char **argv)
             const float len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
             r[9] = c[0] / len; r[10] = c[1] / len; r[11] = c[2] / len;
         }
-        setenv("HRT_ACCEL_BIG", "0", 1);
+        setenv("HRT_TUNE", "accel_big=0", 1);   /* inner levels + plane tree on every table */
+        hrt_tune tune;
+        if (hrt_tune_load(&tune)) return 12;
         hrt_accel a;
         int rc = hrt_accel_order(&a, rows, T, 1);
         if (rc) return 6;
@@ -88,7 +90,7 @@ int main(int argc, char **argv)
             if (a.orig[k] >= T || a.newidx[a.orig[k]] != k) return 7;   /* a permutation and its inverse */
             memcpy(tab + (size_t)k * HRT_TRI_FLOATS, rows + (size_t)a.orig[k] * HRT_TRI_FLOATS, HRT_TRI_FLOATS * sizeof(float));
         }
-        rc = hrt_accel_build(&a, tab);
+        rc = hrt_accel_build(&a, tab, &tune);
         if (rc) return 9;
         if (T && (!a.big || a.pl_levels == 0 || a.pl_count[a.pl_levels - 1] > 64)) return 10;
         /* every row appears exactly once in the plane tree's index */

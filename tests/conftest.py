@@ -10,7 +10,7 @@ if REPO not in sys.path:
 # A one-shot drop-in call builds the per-RX / per-TX direction tables only for launch sets of 2^26 rays
 # or more (they cost more than they save below that: csrc/host/problem.c).  The parity tests want the
 # table path exercised at every size: subprocesses inherit this too.
-os.environ.setdefault("HRT_RXT_MIN_RAYS", "0")
+os.environ.setdefault("HRT_TUNE", "rxt_min_rays=0")   # (csrc/host/tune.c: the test switches live in HRT_TUNE)
 
 
 def pytest_configure(config):

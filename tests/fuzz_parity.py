@@ -31,7 +31,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("HRT_RXT_MIN_RAYS", "0")   # direction tables at every size (default: big launch sets only)
+os.environ.setdefault("HRT_TUNE", "rxt_min_rays=0")   # direction / patch tables at every size (default: big launch sets only)
 from hermespy_rt_amd import abi, lib          # noqa: E402
 from oracle import oracle                      # noqa: E402
 from tests import configs as K                 # noqa: E402

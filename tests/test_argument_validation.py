@@ -35,7 +35,7 @@ def scene(product_lib, tmp_path):
 
 
 @pytest.mark.parametrize("kw,needle", [
-    (dict(np_=0), b"num_rays"), (dict(nb=0), b"num_bounces"), (dict(nb=33), b"num_bounces"),
+    (dict(np_=0), b"num_rays"), (dict(nb=0), b"num_bounces"), (dict(nb=70000), b"num_bounces"),
     (dict(null_scene=True), b"NULL"), (dict(null_los=True), b"NULL"),
     (dict(nrx=0), b"num_rx"), (dict(ntx=0), b"num_rx/num_tx"), (dict(f=0.0), b"frequency"),
     (dict(f=float("nan")), b"frequency"),
@@ -69,7 +69,7 @@ def test_path_list_entry_validates_too(product_lib, scene):
             C.c_size_t(np_), C.c_size_t(nb), C.c_int(0), C.byref(out) if out is not None else None, None)
 
     assert call(np_=0) == -1 and b"num_rays" in product_lib.hrt_last_error()
-    assert call(nb=40) == -1 and b"num_bounces" in product_lib.hrt_last_error()
+    assert call(nb=70000) == -1 and b"num_bounces" in product_lib.hrt_last_error()
     assert call(out=None) == -1 and b"NULL" in product_lib.hrt_last_error()
     assert call(sc=None) == -1 and b"NULL" in product_lib.hrt_last_error()
     product_lib.hrt_path_list_free(C.byref(pl))      # freeing an empty list is fine

@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests.tune import tuned
+
 from hermespy_rt_amd import abi
 from oracle import oracle
 
@@ -78,8 +80,6 @@ def test_product_equals_oracle_on_generated_scenes(variant, lds_max):
     # lds_max: the triangle table staged in LDS up to the hardware limit (the > 64 KiB dynamic-LDS
     # path, one workgroup per CU) or never (every scene through the global-memory path); default:
     # staged up to 40 KiB
-    env = dict(os.environ, HRT_TRACE_VARIANT=str(variant))
-    if lds_max is not None:
-        env["HRT_LDS_TRI_BYTES_MAX"] = str(lds_max)
+    env = tuned(variant=variant) if lds_max is None else tuned(variant=variant, lds_tri_bytes=lds_max)
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)
     assert p.returncode == 0 and "GENERATED_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]

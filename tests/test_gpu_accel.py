@@ -4,19 +4,21 @@ in csrc/hrt_kernels.hip; reference: the "TODO BVH" of src/compute_paths.c:246, s
 Whatever the structure skips must be exactly what the reference's float test rejects, including
 its noise-regime hits on triangles whose plane contains the ray -- so every case is the product
 against the oracle, every output array bit for bit:
-  * the modes: leaf spheres + guard (HRT_TRACE_VARIANT=4), inner levels + plane tree
-    forced onto small tables (HRT_ACCEL_BIG=0: every scene of the suite then walks the trees),
-    the reference's own order (HRT_NO_REORDER=1), the flat walk (2) -- on generated scenes,
+  * the modes: leaf spheres + guard (variant=4), inner levels + plane tree
+    forced onto small tables (accel_big=0: every scene of the suite then walks the trees),
+    the reference's own order (no_reorder=1), the flat walk (2) -- on generated scenes,
     exact ties (duplicated triangles: the lexicographic (distance, original index) tie-break),
     endpoints exactly IN triangle planes, degenerate triangles;
   * a generated city of 10^5 triangles (tests/scenes_gen.city): default, trees, plain flat walk;
-  * the re-sort of the live list between bounces (HRT_SORT_RAYS) on and off.
+  * the re-sort of the live list between bounces (sort_rays) on and off.
 The variant and the table order are latched per process / per problem: subprocesses."""
 import os
 import subprocess
 import sys
 
 import pytest
+
+from tests.tune import tuned
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,35 +44,34 @@ print("ACCEL_OK", len(cases))
 
 
 @pytest.mark.parametrize("env", [
-    dict(HRT_TRACE_VARIANT="4"),                   # leaf spheres + guard
-    dict(HRT_ACCEL_BIG="0"),                       # inner levels + plane tree on every table (auto picks them)
-    dict(HRT_ACCEL_BIG="0", HRT_ACCEL_DEBUG="8"),  # ... with unusable packets cut down to single rays
-    dict(HRT_ACCEL_BIG="0", HRT_NO_REORDER="1"),   # ... on the reference's own table order
-    dict(HRT_TRACE_VARIANT="2"),                   # flat packet culling on the reordered table
-    dict(HRT_SORT_RAYS="1"),                       # live list re-sorted between bounces on every table
-    dict(HRT_SORT_RAYS="0"),                       # ... and never
-    dict(HRT_ACCEL_BIG="0", HRT_SORT_RAYS="1"),    # trees + re-sort
-    dict(HRT_TRACE_VARIANT="0", HRT_NO_REORDER="1"),
-    dict(HRT_NO_TXT="1"),                          # direction tables for the RXs only (default: RXs and TXs)
-    dict(HRT_NO_RXT="1"),                          # ... and none at all
-    dict(HRT_RXT_MIN_RAYS="67108864"),             # the drop-in's own default: tables from 2^26 rays on (none here)
+    dict(variant="4"),                   # leaf spheres + guard
+    dict(accel_big="0"),                       # inner levels + plane tree on every table (auto picks them)
+    dict(accel_big="0", no_reorder="1"),   # ... on the reference's own table order
+    dict(variant="2"),                   # flat packet culling on the reordered table
+    dict(sort_rays="1"),                       # live list re-sorted between bounces on every table
+    dict(sort_rays="0"),                       # ... and never
+    dict(accel_big="0", sort_rays="1"),    # trees + re-sort
+    dict(variant="0", no_reorder="1"),
+    dict(no_txt="1"),                          # direction tables for the RXs only (default: RXs and TXs)
+    dict(no_rxt="1"),                          # ... and none at all
+    dict(rxt_min_rays="67108864"),             # the drop-in's own default: tables from 2^26 rays on (none here)
     # fine leaves (16 rows) scanned flat + plane tree (the default beyond 1 024 triangles), forced onto every
     # table, the table read from global memory as there
-    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0"),
-    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_SORT_RAYS="1"),
-    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_NO_REORDER="1"),
+    dict(accel_fine_min="0", lds_tri_bytes="0"),
+    dict(accel_fine_min="0", lds_tri_bytes="0", sort_rays="1"),
+    dict(accel_fine_min="0", lds_tri_bytes="0", no_reorder="1"),
     # ... its queue of too-wide packets (hrt_wide_kernel) overflowing after 3 entries (the rest runs in the
     # pushing wave), and absent
-    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_WIDE_CAP="3"),
-    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_WIDE_CAP="0", HRT_SORT_RAYS="1"),
-    dict(HRT_LOS_BIG_MIN_TRI="0"),                 # the big tables' sliced LoS kernel on every table
+    dict(accel_fine_min="0", lds_tri_bytes="0", wide_cap="3"),
+    dict(accel_fine_min="0", lds_tri_bytes="0", wide_cap="0", sort_rays="1"),
+    dict(los_big_min_tri="0"),                 # the big tables' sliced LoS kernel on every table
     # fine leaves + queue on two logical devices, each running several batches through a small workspace
-    dict(HRT_ACCEL_FINE_MIN="0", HRT_LDS_TRI_BYTES_MAX="0", HRT_DEVICES="0,0", HRT_WORKSPACE_BYTES="8000000"),
-], ids=["leaf", "trees", "trees_split", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order",
+    dict(accel_fine_min="0", lds_tri_bytes="0", HRT_DEVICES="0,0", HRT_WORKSPACE_BYTES="8000000"),
+], ids=["leaf", "trees", "trees_ref_order", "flat", "resort", "no_resort", "trees_resort", "plain_ref_order",
         "rx_tables_only", "no_tables", "tables_by_size", "fine", "fine_resort", "fine_ref_order", "fine_queue_overflow",
         "fine_no_queue", "los_sliced", "fine_devices_batches"])
 def test_modes_are_bit_identical_to_the_oracle(env):
-    p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=dict(os.environ, **env),
+    p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=tuned(**env),
                        capture_output=True, text=True)
     assert p.returncode == 0 and "ACCEL_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
@@ -100,13 +101,13 @@ print("CITY_OK", live, "product %%.1f s, oracle %%.1f s" %% (t1 - t0, time.time(
 """
 
 
-@pytest.mark.parametrize("env", [dict(), dict(HRT_WIDE_CAP="40"), dict(HRT_ACCEL_FINE="0"), dict(HRT_ACCEL_BIG="65536"),
-                                 dict(HRT_TRACE_VARIANT="2", HRT_SORT_RAYS="0")],
+@pytest.mark.parametrize("env", [dict(), dict(wide_cap="40"), dict(accel_fine="0"), dict(accel_big="65536"),
+                                 dict(variant="2", sort_rays="0")],
                          ids=["default_fine_resorted", "fine_queue_overflow", "leaves_resorted", "trees_resorted", "flat"])
 def test_city_of_1e5_triangles(env):
     """10^5 triangles: by default the fine leaves (16 rows, flat scan) + plane tree over a live list
     re-sorted between bounces; the leaf spheres of 64 rows + guard (round 2's default); with
-    HRT_ACCEL_BIG lowered the sphere levels + plane tree; and the plain flat walk."""
-    p = subprocess.run([sys.executable, "-c", CITY % dict(repo=REPO)], env=dict(os.environ, **env),
+    accel_big lowered the sphere levels + plane tree; and the plain flat walk."""
+    p = subprocess.run([sys.executable, "-c", CITY % dict(repo=REPO)], env=tuned(**env),
                        capture_output=True, text=True)
     assert p.returncode == 0 and "CITY_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]

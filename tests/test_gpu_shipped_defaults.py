@@ -1,4 +1,4 @@
-"""The drop-in exactly as a user gets it.  tests/conftest.py sets HRT_RXT_MIN_RAYS=0 for the whole
+"""The drop-in exactly as a user gets it.  tests/conftest.py sets HRT_TUNE=rxt_min_rays=0 for the whole
 suite so that the direction tables / candidate masks are exercised at every size; a one-shot
 compute_paths() call builds them only from 2^26 rays on (2^18 on tables of <= 64 triangles).  Here
 the dense-parity cases run in a child process WITHOUT that variable -- the shipped default -- plus
@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r"""
 import os, sys
 sys.path.insert(0, %(repo)r)
-assert "HRT_RXT_MIN_RAYS" not in os.environ and "HRT_FUSE" not in os.environ and "HRT_TRACE_VARIANT" not in os.environ
+assert "HRT_TUNE" not in os.environ and "HRT_FUSE" not in os.environ
 from hermespy_rt_amd import abi, lib
 from oracle import oracle
 from tests import configs as K
@@ -36,6 +36,6 @@ print("DEFAULTS_OK", len(cases))
 
 
 def test_dense_parity_with_the_shipped_defaults():
-    env = {k: v for k, v in os.environ.items() if k not in ("HRT_RXT_MIN_RAYS", "HRT_FUSE", "HRT_TRACE_VARIANT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("HRT_TUNE", "HRT_FUSE")}
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)
     assert p.returncode == 0 and "DEFAULTS_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]

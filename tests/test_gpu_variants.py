@@ -1,4 +1,4 @@
-"""The three intersection loops of the bounce kernel -- HRT_TRACE_VARIANT=0 (the reference's
+"""The three intersection loops of the bounce kernel -- HRT_TUNE variant=0 (the reference's
 plain sequence), 1 (staged division-free rejects), 2 (packet culling + staged; the default)
 -- must give bit-identical results.  The variant is latched per process, so each one runs in
 a subprocess through the drop-in C ABI against the oracle, on a coherent and an incoherent
@@ -8,6 +8,8 @@ import subprocess
 import sys
 
 import pytest
+
+from tests.tune import tuned
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +46,6 @@ print("VARIANT_OK")
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_variant_is_bit_identical(variant):
-    env = dict(os.environ, HRT_TRACE_VARIANT=str(variant))
+    env = tuned(variant=variant)
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)
     assert p.returncode == 0 and "VARIANT_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

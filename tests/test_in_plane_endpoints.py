@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from tests.tune import tuned
+
 from hermespy_rt_amd import abi
 from oracle import oracle
 
@@ -45,6 +47,6 @@ print("IN_PLANE_OK")
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_product_equals_oracle_in_plane(variant):
-    env = dict(os.environ, HRT_TRACE_VARIANT=str(variant))
+    env = tuned(variant=variant)
     p = subprocess.run([sys.executable, "-c", CODE % dict(repo=REPO)], env=env, capture_output=True, text=True)
     assert p.returncode == 0 and "IN_PLANE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
