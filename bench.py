@@ -214,9 +214,6 @@ def main():
     rehearse = os.environ.get("HRT_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-        # (the fused launches spin on prefix words in dispatch order: N processes time-sharing one GPU make
-        # that wait take seconds -- INTEGRATION.md "Threads and processes")
-        os.environ.setdefault("HRT_FUSE", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
@@ -448,6 +445,26 @@ def main():
             out["step_incl_launch"] = dict(ms=l_dt * 1e3, paths_per_s=paths / l_dt, steps=n_li,
                                            what="hrt_launch_dirs_device + hrt_launch_order_device + permutation "
                                                 "of the direction table into launch order + the step")
+            # (b') what ONE rank of a strong-scaling run does: the step of rank 0's round-robin shard of this
+            # launch set at world 2 / 4 / 8, measured on this GPU (a prediction the driver's N-GPU run can be held
+            # against: N x speed-up = world_1 / world_N if nothing but the shard's own step limits a rank)
+            shard_ms = {}
+            for w_ in (2, 4, 8):
+                ts = Tracer(base["scene_path"], base["rx_pos"], base["tx_pos"], base["rx_vel"], base["tx_vel"],
+                            base["f_ghz"], base["num_paths"], base["num_bounces"], rank=0, world=w_)
+                for _ in range(3):
+                    ts.trace()
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                for _ in range(20):
+                    ts.trace()
+                torch.cuda.synchronize()
+                shard_ms["world_%d" % w_] = (time.perf_counter() - q0) / 20 * 1e3
+                ts.close()
+                del ts
+            out["strong_scaling_shard_ms"] = dict(world_1=dt / args.steps * 1e3, **shard_ms,
+                                                  what="step of rank 0's shard of this workload's launch set (total rays "
+                                                       "fixed), one GPU")
             # (c) the drop-in ABI end to end (host arrays, PCIe inclusive): first call and second call
             from hermespy_rt_amd import abi, lib as _lib
             tr.close()

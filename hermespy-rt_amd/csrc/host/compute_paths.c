@@ -300,8 +300,10 @@ static int parse_devices(int *dev)
  * Device workspace and page-locked staging of the last call, one slot per worker, reused when the
  * next call fits (same device, capacity >= needed): a warm call saves ~25 ms of hipMalloc /
  * hipHostMalloc / hipFree on C3.  Released by hrt_cache_clear(); HRT_NO_CACHE=1 disables;
- * slots holding more than HRT_POOL_MAX_BYTES (default 24 GiB device + pinned: a batch is at most
- * 16 GiB of workspace by default; C4 holds 14 GB and its warm call fell from 0.24 to 0.04 s) are not kept. */
+ * slots holding more than HRT_POOL_MAX_BYTES (default 5 GiB device + pinned: a warm C3 call holds 4.0 GB; a
+ * reference-API caller never calls hrt_cache_clear(), so the default stays near what the headline configuration
+ * needs.  C4 holds 14 GB -- its warm call is 0.04 s with them kept, 0.24 s without: such a caller raises it) are
+ * not kept. */
 typedef struct {
     int valid, device, with_rays;
     uint64_t cap, ws_bytes, dirs_rows;
@@ -420,7 +422,7 @@ void hrt_worker_release(dev_ctx *c)
     free(w->active); free(w->next_active); w->active = w->next_active = NULL;
     free(w->dirs_batch); w->dirs_batch = NULL;
     const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (5 + 2 * HRT_REC_FIELDS + 6 + 8);
-    if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 24ull << 30)) {
+    if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 5ull << 30)) {
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
         if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);
         pool_slot *ps = &g_pool[c->index];
