@@ -792,17 +792,11 @@ __device__ __forceinline__ PatchRef patch_locate(TriPtr tri, const hrt_kpatch &X
     return R;
 }
 
-// the trace of a wave whose lanes have located their patches (R; lanes past the end of the list: !valid)
-template <typename TriPtr>
-__device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__restrict__ orig, const hrt_kpatch &X,
-                                                 const PatchRef R, uint32_t apex_k, uint32_t num_tri, F3 o, F3 d,
-                                                 bool valid, uint32_t lane, [[maybe_unused]] int kind)
+// the mask words of a located lane for apex `apex_k` (a lane that is not served: the whole table; a lane past the
+// end of the list: nothing) -- a request only: nothing waits for the loads here
+__device__ __forceinline__ void patch_load(const hrt_kpatch &X, const PatchRef R, uint32_t apex_k, uint32_t num_tri, bool valid,
+                                           uint32_t (&w)[8])
 {
-    float best = 1e9f;
-    uint32_t who = HRT_NO_HIT, who_o = 0u;
-    const unsigned long long inval = HRT_BALLOT(!valid);
-    if (inval == ~0ull) return {who, best};
-    uint32_t w[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w[k] = 0u;
     if (valid) {
@@ -818,8 +812,18 @@ __device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__r
             for (int k = 0; k < 8; ++k)
                 w[k] = num_tri >= 32u * (uint32_t)(k + 1) ? ~0u : (num_tri > 32u * (uint32_t)k ? (1u << (num_tri - 32u * (uint32_t)k)) - 1u : 0u);
         }
-        HRT_STAT(kind, 6, R.served ? 1 : 0);
     }
+}
+
+// the trace of a wave from its lanes' mask words: the union over the wave, walked through the staged test
+template <typename TriPtr, typename OrigPtr>
+__device__ __forceinline__ Hit closest_hit_words(TriPtr tri, OrigPtr orig, uint32_t (&w)[8], uint32_t num_tri,
+                                                 F3 o, F3 d, bool valid, uint32_t lane, [[maybe_unused]] int kind)
+{
+    float best = 1e9f;
+    uint32_t who = HRT_NO_HIT, who_o = 0u;
+    const unsigned long long inval = HRT_BALLOT(!valid);
+    if (inval == ~0ull) return {who, best};
     wave_or256(w);
     HRT_STAT(kind, 0, 1);
     HRT_STAT(kind, 1, 1);
@@ -833,7 +837,20 @@ __device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, const uint32_t *__r
             HRT_STAGED_BODY(j)
         }
     }
+    (void)num_tri;
     return {who, best};
+}
+
+// the trace of a wave whose lanes have located their patches (R; lanes past the end of the list: !valid)
+template <typename TriPtr, typename OrigPtr>
+__device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, OrigPtr orig, const hrt_kpatch &X,
+                                                 const PatchRef R, uint32_t apex_k, uint32_t num_tri, F3 o, F3 d,
+                                                 bool valid, uint32_t lane, [[maybe_unused]] int kind)
+{
+    uint32_t w[8];
+    patch_load(X, R, apex_k, num_tri, valid, w);
+    HRT_STAT(kind, 6, (valid && R.served) ? 1 : 0);
+    return closest_hit_words(tri, orig, w, num_tri, o, d, valid, lane, kind);
 }
 
 template <bool MULTI, typename TriPtr>
@@ -1627,6 +1644,8 @@ __device__ __forceinline__ float4 fresnel_inl(float4 m0, float4 m1, float4 m2, f
 __device__ __noinline__ float4 fresnel(float4 m0, float4 m1, float4 m2, float th) { return fresnel_inl(m0, m1, m2, th); }
 
 // src/compute_paths.c:359-415; s = scattering coefficient, alpha = s1_alpha (small integer)
+// (kept out of line, like incidence_angle: inlined into the records kernel they spill -- C3 1.125 -> 1.39 ms with the
+// angle inlined, 1.78 with both, at 6 waves; 1.33 at 4)
 __device__ __noinline__ float4 scatter_pattern(float s, float alpha, float th_s, float th_i)
 {
     const float cs = hrt_cosf_nb(th_s);
@@ -2692,6 +2711,9 @@ __global__ __launch_bounds__(HRT_BLOCK, 8) void hrt_image_kernel(const hrt_kpara
     }
 }
 
+#ifndef HRT_RECORDS_PREFETCH
+#define HRT_RECORDS_PREFETCH 1   /* masks of RX r + 1 requested before the walk of RX r: C3 1.125 -> 1.112 ms at 6 waves (5 waves: 1.155) */
+#endif
 #ifndef HRT_RECORDS_WAVES
 #define HRT_RECORDS_WAVES 6
 #endif
@@ -2711,6 +2733,9 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_RECORDS_WAVES) void hrt_records_kern
     float4 *l_tri = lds;
     float4 *l_rx = lds + HRT_ROW * T;
     float4 *l_mat = l_rx + P.num_rx;
+    // (the reference-order index of every row, for the tie rule: in LDS, so that the exact stage of the walk has no
+    // global load -- whose s_waitcnt vmcnt(0) would also wait for the masks requested ahead)
+    uint32_t *l_orig = reinterpret_cast<uint32_t *>(l_mat + 4u * HRT_NUM_MATERIALS);
     {
         const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
         const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
@@ -2718,6 +2743,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_RECORDS_WAVES) void hrt_records_kern
         for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
             l_rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
         for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) l_mat[k] = g_mat[k];
+        for (uint32_t k = tid; k < T; k += HRT_BLOCK) l_orig[k] = P.acc.orig[k];
     }
     __syncthreads();
     const float4 *tri = l_tri;
@@ -2752,12 +2778,24 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_RECORDS_WAVES) void hrt_records_kern
                 mat_alpha = m3.y;
             }
         }
+#if HRT_RECORDS_PREFETCH
+        uint32_t wnext[8];   // the masks of the NEXT RX are requested before this RX's walk (a global gather: ~1-2 us)
+        patch_load(P.patch, ref, 0u, T, valid, wnext);
+#endif
         for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
             const float4 rp = l_rx[rx];
             float d2rx;
             F3 w = shadow_dir(o, {rp.x, rp.y, rp.z}, d2rx);
             if (!valid) w = {0.f, 0.f, 1.f};
-            const Hit h = closest_hit_patch(tri, P.acc.orig, P.patch, ref, rx, T, o, w, valid, lane, 2);
+#if HRT_RECORDS_PREFETCH
+            uint32_t wcur[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wcur[q] = wnext[q];
+            if (rx + 1u < P.num_rx) patch_load(P.patch, ref, rx + 1u, T, valid, wnext);
+            const Hit h = closest_hit_words(tri, l_orig, wcur, T, o, w, valid, lane, 2);
+#else
+            const Hit h = closest_hit_patch(tri, l_orig, P.patch, ref, rx, T, o, w, valid, lane, 2);
+#endif
             bool unblocked = false;
             if (valid) {
                 if (h.tri != HRT_NO_HIT) {   // quirk Q7: any shadow hit, at any distance, overwrites theta
@@ -4318,7 +4356,7 @@ int hrt_hip_launch_records(const hrt_kparams *P, uint32_t bounce, void *stream)
     uint64_t rblocks = (P->cap + HRT_BLOCK - 1) / HRT_BLOCK;
     if (rblocks > 2u * max_grid) rblocks = 2u * max_grid;   // (1 024 .. 4 096 workgroups: 2-5 % slower)
     const size_t rlds = (size_t)T * HRT_TRI_FLOATS * 4u + (size_t)P->num_rx * 16u +
-                        (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u);
+                        (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + (size_t)T * 4u;
     if (rlds > 64u * 1024u) return (int)hipErrorInvalidValue;   // (cannot happen: T <= HRT_PATCH_MAX_TRI)
     hipLaunchKernelGGL(hrt_records_kernel, dim3((uint32_t)rblocks), dim3(HRT_BLOCK), rlds, (hipStream_t)stream, *P, bounce);
     return (int)hipGetLastError();
