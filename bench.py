@@ -365,12 +365,17 @@ def main():
             valu_frac = max(fr)[1]   # of the kernel that issues the most instructions
     fused0 = os.environ.get("HRT_FUSE", "") not in ("0",)
     fused_all = fused0 and tr.num_tri <= 64
+    patched = 64 < tr.num_tri <= 256 and "no_patch" not in os.environ.get("HRT_TUNE", "")
     kern_desc = ("hrt_fused_kernel (one kernel per launch: trace + shading + stable compaction)" if fused_all else
                  ("launch 0: hrt_fused_kernel; later launches: " if fused0 else "") +
-                 "hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)")
+                 ("hrt_records_kernel (shadow traces + scatter records; in the timed region on a second stream beside the "
+                  "others) + hrt_image_kernel / hrt_trace_kernel (primary rays) + hrt_shade_kernel (Fresnel, reflection, "
+                  "compaction): one bounce launch = the three; trace_kernel_ms = records + primary rays" if patched else
+                  "hrt_trace_kernel + hrt_shade_kernel (one bounce launch = the pair)"))
     roofline = dict(bound=("valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm"), kernel=kern_desc,
                     achieved=ach, peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=hbm_frac, hbm_frac=hbm_frac, valu_frac=valu_frac,
+                    frac_of_step=B_local / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                     traffic=traffic, traffic_source=traffic_src,
                     traffic_stale=traffic_stale, traffic_measured_in_run=False, kernels_sha16=kern_sha,
                     algorithmic_bytes_per_launch=B_local / n_launch,
@@ -385,7 +390,9 @@ def main():
                     trace_variant=os.environ.get("HRT_TUNE", "auto (patch tables on 65-256 triangles; flat packet culling; trees on big sparse tables)"),
                     valu=valu,
                     note=("a fused launch reports its one kernel under trace_kernel_ms (shade_kernel_ms = 0); "
-                          "frac is the north-star's HBM figure (algorithmic bytes / kernel time / 8 TB/s); "
+                          "frac is the north-star's HBM figure (algorithmic bytes / SUM of the kernels' own durations, "
+                          "measured one after the other on one stream / 8 TB/s); frac_of_step the same bytes over the timed "
+                          "step, in which the records kernels run beside the others; "
                           "valu_frac = VALU instructions issued x 2 cycles / SIMD-cycles of the busiest kernel"))
 
     kstats = None

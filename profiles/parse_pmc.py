@@ -3,7 +3,7 @@
 our kernels), profiles/<tag>_pmc_wave_<workload>.csv, profiles/<tag>_bench_<workload>_kernel_stats.csv and
 profiles/pmc_traffic.json: corrected HBM bytes per launch, which bench.py reports as roofline.traffic
 for the same workload.  A launch = one hrt_fused_kernel dispatch, or an hrt_trace_kernel dispatch and
-the hrt_shade_kernel (+ re-sort kernels) behind it."""
+the hrt_shade_kernel (+ re-sort kernels) behind it; with patch tables the launch begins with its hrt_records_kernel."""
 import csv
 import glob
 import hashlib
@@ -28,6 +28,10 @@ def newest(pattern):
 def kind(name):
     if "hrt_fused_kernel" in name:
         return "fused"
+    if "hrt_records_kernel" in name:
+        return "records"
+    if "hrt_image_kernel" in name:
+        return "image"
     if "hrt_trace_kernel" in name:
         return "trace"
     if "hrt_shade_kernel" in name:
@@ -57,11 +61,14 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in rows if kind(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     n_steps = sum(1 for r in rows if is_launch0(r["Kernel_Name"])) or sum(1 for r in rows if "los" in r["Kernel_Name"])
-    per, kinds = [], {}
+    per, kinds, prev = [], {}, None
     for r in rows:
         k = kind(r["Kernel_Name"])
-        if k in ("fused", "trace"):
+        # a launch begins with its fused kernel, with its records kernel (patch tables: shadow traces + records), or
+        # with the kernel of its primary rays when no records kernel went before
+        if k in ("fused", "records") or (k in ("trace", "image") and prev != "records"):
             per.append(0.0)
+        prev = k
         per[-1] += float(r["Counter_Value"])
         kinds[k] = kinds.get(k, 0.0) + float(r["Counter_Value"]) / n_steps
     per_step = len(per) // n_steps
@@ -74,10 +81,10 @@ path = os.path.join(HERE, "pmc_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[workload] = dict(
     kernels_sha16=hashlib.sha256(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", "hrt_kernels.hip"), "rb").read()).hexdigest()[:16],
-    n_gpus=1, kernel="per launch: hrt_fused_kernel, or hrt_trace_kernel + hrt_shade_kernel", round=tag,
+    n_gpus=1, kernel="per launch: hrt_fused_kernel, or hrt_records_kernel + hrt_image_kernel / hrt_trace_kernel + hrt_shade_kernel", round=tag,
     by_kernel_bytes_per_step={k: dict(fetch=raw["FETCH_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["FETCH_SIZE"]["corr"] * 1024,
                                       write=raw["WRITE_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["WRITE_SIZE"]["corr"] * 1024)
-                              for k in ("fused", "trace", "shade", "sort")},
+                              for k in ("fused", "records", "image", "trace", "shade", "sort")},
     source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/%s_pmc_*_%s.csv); "
            "KiB counters, calibrated on a known-traffic launch of the same access pattern: "
            "FETCH_SIZE x%.3f (gfx950 half-count), WRITE_SIZE x%.3f" % (tag, workload, raw["FETCH_SIZE"]["corr"], raw["WRITE_SIZE"]["corr"]),

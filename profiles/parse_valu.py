@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/collect_all.sh <tag> <workload> -> profiles/<tag>_pmc_valu_<workload>.csv (trimmed to our kernels)
 and profiles/pmc_valu.json: VALU instructions per step and SIMD-cycles per VALU instruction of the
-fused, trace and shade kernels, which bench.py reports next to the HBM roofline (roofline.valu)."""
+fused, records, image, trace and shade kernels, which bench.py reports next to the HBM roofline (roofline.valu)."""
 import csv
 import glob
 import hashlib
@@ -36,7 +36,7 @@ def launch0(name):
 n_steps = len({r["Dispatch_Id"] for r in rows if launch0(r["Kernel_Name"])}) or \
     len({r["Dispatch_Id"] for r in rows if "los" in r["Kernel_Name"]})
 out = {}
-for kern in ("fused", "trace", "shade"):
+for kern in ("fused", "records", "image", "trace", "shade"):
     acc = {}
     for r in rows:
         if ("hrt_%s_kernel" % kern) in r["Kernel_Name"]:
