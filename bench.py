@@ -294,13 +294,14 @@ def main():
     for t in timers:
         step(t)
     torch.cuda.synchronize()
-    bounce_ms, los_ms, compact_ms, shade_ms = [], [], [], []
+    bounce_ms, los_ms, compact_ms, shade_ms, records_ms = [], [], [], [], []
     for t in timers:
         r = tr.read_timer(t)
         los_ms.append(r["los_ms"])
         bounce_ms.append(r["trace_ms"])
         shade_ms.append(r["shade_ms"])
         compact_ms.append(sum(r["scan_ms"]))
+        records_ms.append(r["records_ms"])
 
     # ---- work done (identical every step) ----
     counts = tr.counts()
@@ -321,9 +322,10 @@ def main():
     # ---- roofline of the dominant kernels, rank 0's launches.  One launch of "the bounce" is
     # the pair hrt_trace_kernel (intersection) + hrt_shade_kernel (records, Fresnel, reflect):
     # the algorithmic bytes of SURVEY 8(d) are those of the pair, so is the duration. ----
-    tm = np.asarray(bounce_ms, dtype=np.float64)          # [steps, nb+1] trace kernel
+    tm = np.asarray(bounce_ms, dtype=np.float64)          # [steps, nb+1] trace kernel (patch tables: primary rays only)
     sm = np.asarray(shade_ms, dtype=np.float64)           # [steps, nb+1] shade kernel
-    bm = tm + sm
+    rm = np.asarray(records_ms, dtype=np.float64)         # [steps, nb+1] records kernel (patch tables; else 0)
+    bm = tm + sm + rm
     kern_ms_step = float(bm.sum(axis=1).mean())
     n_launch = bm.shape[1]
     unb_local = unblocked
@@ -385,6 +387,7 @@ def main():
                     per_launch_ms=[float(x) for x in bm.mean(axis=0)],
                     trace_kernel_ms=[float(x) for x in tm.mean(axis=0)],
                     shade_kernel_ms=[float(x) for x in sm.mean(axis=0)],
+                    records_kernel_ms=[float(x) for x in rm.mean(axis=0)],
                     kernel_tests_per_s=tests_local / (kern_ms_step * 1e-3),
                     compaction_ms_per_step=float(np.mean(compact_ms)), los_ms=float(np.mean(los_ms)),
                     trace_variant=os.environ.get("HRT_TUNE", "auto (patch tables on 65-256 triangles; flat packet culling; trees on big sparse tables)"),
@@ -394,6 +397,18 @@ def main():
                           "measured one after the other on one stream / 8 TB/s); frac_of_step the same bytes over the timed "
                           "step, in which the records kernels run beside the others; "
                           "valu_frac = VALU instructions issued x 2 cycles / SIMD-cycles of the busiest kernel"))
+
+    if rm.sum() > 0:
+        # the DOMINANT kernel on its own: hrt_records_kernel.  Algorithmic bytes of one launch b (the part
+        # of the path this kernel performs): 44 B of state per entry in, 36 B per unblocked / 20 B per blocked record out
+        rec_launches = [b for b in range(1, nb + 1) if w["live"][b] > 0]
+        rec_bytes = 44.0 * sum(w["live"][b] for b in rec_launches) + 36.0 * unb_local + 20.0 * (w["records"] - unb_local)
+        rec_ms = float(rm.sum(axis=1).mean())
+        roofline["dominant_kernel"] = dict(
+            name="hrt_records_kernel", launches_per_step=len(rec_launches), avg_launch_ms=rec_ms / max(1, len(rec_launches)),
+            ms_per_step=rec_ms, algorithmic_bytes_per_step=rec_bytes,
+            achieved=rec_bytes / (rec_ms * 1e-3) / 1e9, unit="GB/s", frac=rec_bytes / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            what="HIP events around the kernel, one stream (the event pass); its VALU issue fraction is roofline.valu.records")
 
     kstats = None
     try:

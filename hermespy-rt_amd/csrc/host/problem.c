@@ -1075,8 +1075,8 @@ int hrt_timer_read(hrt_timer *t, hrt_kernel_times *times)
 #define STEP(call) do { if (!hip) hip = (call); } while (0)
     STEP(hrt_hip_event_elapsed_ms(t->ev[0], t->ev[1], &times->los_ms));
     for (uint32_t b = 0; b <= nb && !hip; ++b) {
-        STEP(hrt_hip_event_elapsed_ms(t->ev[2 + 4 * b], t->ev[3 + 4 * b], &times->trace_ms[b]));
-        times->compact_ms[b] = 0.f;   /* nothing runs between the two kernels any more */
+        STEP(hrt_hip_event_elapsed_ms(t->ev[2 + 4 * b], t->ev[4 + 4 * b], &times->records_ms[b]));
+        STEP(hrt_hip_event_elapsed_ms(t->ev[4 + 4 * b], t->ev[3 + 4 * b], &times->trace_ms[b]));
         STEP(hrt_hip_event_elapsed_ms(t->ev[3 + 4 * b], t->ev[5 + 4 * b], &times->shade_ms[b]));
     }
 #undef STEP
@@ -1259,8 +1259,8 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
             aux = 1;
         }
     }
-    /* events (only with a timer): [0,1] around LoS; per launch b: start, end of trace (= start
-     * of scan), end of scan (= start of shade), end of shade */
+    /* events (only with a timer): [0,1] around LoS; per launch b: [2] start, [4] end of the records kernel (patch
+     * tables; else = start), [3] end of the trace / fused kernel, [5] end of the shade kernel */
     void **ev = timer ? timer->ev : NULL;
     if (timer && timer->num_bounces != nb)
         return hrt_fail(HRT_E_INVALID, "timer was created for %u bounces, trace has %u", timer->num_bounces, nb);
@@ -1294,6 +1294,7 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
             if (rr == 0) own_records = 1;
             if (rr == 0 && rs != stream) forked = 1;
         }
+        if (ev) STEP(hrt_hip_event_record(ev[4 + 4 * b], stream));   /* end of the records kernel (or: nothing ran) */
         if (own_records && b == nb) {   /* the last launch: records only */
             if (ev) { STEP(hrt_hip_event_record(ev[3 + 4 * b], stream)); STEP(hrt_hip_event_record(ev[5 + 4 * b], stream)); }
             continue;

@@ -150,7 +150,8 @@ class Tracer:
             n = int(times.num_bounce_launches)
             self.last_times = (float(times.los_ms), [float(times.trace_ms[i]) for i in range(n)])
             self.last_shade_ms = [float(times.shade_ms[i]) for i in range(n)]
-            self.last_compact_ms = [float(times.compact_ms[i]) for i in range(n)]
+            self.last_compact_ms = [0.0] * n
+            self.last_records_ms = [float(times.records_ms[i]) for i in range(n)]
             return self.last_times
         return None
 
@@ -190,13 +191,14 @@ class Tracer:
         return (self.dirs_launch if self.flags & _lib.DIRS_IN_LAUNCH_ORDER else self.dirs).data_ptr()
 
     def read_timer(self, timer, destroy=True):
-        """-> dict(los_ms, trace_ms[], shade_ms[], scan_ms[]); waits for the timer's last event."""
+        """-> dict(los_ms, trace_ms[], shade_ms[], records_ms[], scan_ms[]); waits for the timer's last event."""
         times = _lib.KernelTimes()
         _lib.check(self.L.hrt_timer_read(timer, C.byref(times)), "hrt_timer_read")
         n = int(times.num_bounce_launches)
         out = dict(los_ms=float(times.los_ms), trace_ms=[float(times.trace_ms[i]) for i in range(n)],
                    shade_ms=[float(times.shade_ms[i]) for i in range(n)],
-                   scan_ms=[float(times.compact_ms[i]) for i in range(n)])
+                   records_ms=[float(times.records_ms[i]) for i in range(n)],
+                   scan_ms=[0.0] * n)
         if destroy:
             self.L.hrt_timer_destroy(timer)
         return out

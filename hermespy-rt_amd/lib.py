@@ -51,7 +51,7 @@ class Layout(C.Structure):
 
 class KernelTimes(C.Structure):
     _fields_ = [("los_ms", C.c_float), ("trace_ms", C.c_float * 33), ("shade_ms", C.c_float * 33),
-                ("compact_ms", C.c_float * 33), ("num_bounce_launches", C.c_uint32)]
+                ("records_ms", C.c_float * 33), ("num_bounce_launches", C.c_uint32)]
 
 
 class Stats(C.Structure):

@@ -178,10 +178,11 @@ int hrt_layout_query(const hrt_problem *p, const hrt_shard *s, hrt_layout *out);
 /* Per-launch device times of one hrt_trace call, filled only when requested. */
 typedef struct {
     float los_ms;
-    float trace_ms[33];         /* trace kernel (all intersection work) of launch b = 0..num_bounces */
-    float shade_ms[33];         /* shade kernel (records, Fresnel, reflect) of launch b */
-    float compact_ms[33];       /* between the trace and the shade kernel of launch b (nothing runs
-                                 * there any more: ~0) */
+    float trace_ms[33];         /* trace kernel of launch b = 0..num_bounces (patch tables: the primary rays only;
+                                 * a fused launch: its one kernel) */
+    float shade_ms[33];         /* shade kernel (Fresnel, reflect, compaction; records unless records_ms) of launch b */
+    float records_ms[33];       /* hrt_records_kernel of launch b (patch tables: shadow traces + scatter records);
+                                 * 0 where the trace and shade kernels do that work */
     uint32_t num_bounce_launches;
 } hrt_kernel_times;
 

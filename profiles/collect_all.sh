@@ -13,6 +13,12 @@ mkdir -p gpurun_out
 B="python3 bench.py --workload $w --no-cpu-baseline --no-end-to-end --event-steps 1"
 d=gpurun_out/prof_${tag}_$w
 rm -rf $d
+# (one stream for the kernel-stats run, HRT_OVERLAP=0: a kernel's duration is then its own and can be held against the
+# per-kernel HIP events of the bench line, which come from a one-stream pass too.  In the timed region the records
+# kernels run on a second stream beside the others and every duration stretches: second run, *_overlap)
+HRT_OVERLAP=0 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- $B --steps 20 --warmup 5 > $d.json 2> $d.err || (tail -20 $d.err; exit 1)
+d=gpurun_out/prof_${tag}_${w}_overlap
+rm -rf $d
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- $B --steps 20 --warmup 5 > $d.json 2> $d.err || (tail -20 $d.err; exit 1)
 for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/pmc_${tag}_${w}_$c

@@ -104,5 +104,10 @@ try:
             w.writerow({k: r[k] for k in w.fieldnames})
     f = newest(os.path.join("prof_%s_%s" % (tag, workload), "*", "*kernel_stats.csv"))
     shutil.copy(f, os.path.join(HERE, "%s_bench_%s_kernel_stats.csv" % (tag, workload)))
+    try:   # the same with the records kernels on their second stream (durations of concurrent kernels stretch)
+        f = newest(os.path.join("prof_%s_%s_overlap" % (tag, workload), "*", "*kernel_stats.csv"))
+        shutil.copy(f, os.path.join(HERE, "%s_bench_%s_kernel_stats_overlap.csv" % (tag, workload)))
+    except ValueError:
+        pass
 except ValueError as e:
     print("no wave / stats pass found:", e)
