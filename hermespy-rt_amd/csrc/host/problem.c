@@ -373,17 +373,30 @@ static int patch_build(hrt_problem *p, const Vec3 *rx_pos, const Vec3 *tx_pos)
         const float ro_img = (float)(1e-3 + 1e-5 * (cmax + ext1));
         /* a served lane's COMPUTED plane distance is <= hmax; the true one then <= hball */
         const float hball = (float)((double)hmax * 1.01 + 16.0 * u * (Smax + cmax));
-        const uint64_t b_pdef = round_up((uint64_t)T * 32, 256), b_mask = npatch * n_apex * HRT_PATCH_WORDS * 8;
+        const uint64_t b_pdef = round_up((uint64_t)T * 32, 256), b_mask = round_up(npatch * n_apex * HRT_PATCH_WORDS * 8, 256);
+        const uint64_t b_txc = (uint64_t)n_tx * HRT_RXT_BINS * HRT_PATCH_WORDS * 8;   /* the TX cell masks (launch 0) */
+        const float *bins = rxt_bins(1);   /* the cells' cones alone (+ the rounding of the lookup) */
+        if (!bins) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto out; }
         const uint64_t b_ptri = round_up(npatch * 4, 256), b_apex = round_up((uint64_t)n_apex * 12, 256);
-        if ((e = hrt_hip_malloc(&p->d_patch, b_pdef + b_mask))) { p->d_patch = NULL; rc = hrt_fail_hip(e, "hipMalloc(patch tables)"); goto out; }
-        if ((e = hrt_hip_malloc(&d_tmp, b_ptri + b_apex))) { rc = hrt_fail_hip(e, "hipMalloc(patch build)"); goto out; }
+        const uint64_t b_bins = (uint64_t)HRT_RXT_BINS * 24;
+        if ((e = hrt_hip_malloc(&p->d_patch, b_pdef + b_mask + b_txc))) { p->d_patch = NULL; rc = hrt_fail_hip(e, "hipMalloc(patch tables)"); goto out; }
+        if ((e = hrt_hip_malloc(&d_tmp, b_ptri + b_apex + b_bins))) { rc = hrt_fail_hip(e, "hipMalloc(patch build)"); goto out; }
         uint8_t *q = (uint8_t *)p->d_patch;
         if ((e = hrt_hip_h2d(q, pdef, (uint64_t)T * 32)) || (e = hrt_hip_h2d(d_tmp, ptri, npatch * 4)) ||
             (e = hrt_hip_h2d((uint8_t *)d_tmp + b_ptri, apex, (uint64_t)n_apex * 12))) { rc = hrt_fail_hip(e, "hipMemcpy(patch build)"); goto out; }
         if ((e = hrt_hip_patch_build(p->d_tri, T, (const float *)q, (const uint32_t *)d_tmp, (uint32_t)npatch,
                                      (const float *)((uint8_t *)d_tmp + b_ptri), n_rx, n_tx, hball, ro_rx, ro_img,
                                      (unsigned long long *)(q + b_pdef), NULL))) { rc = hrt_fail_hip(e, "hrt_patch_build_kernel"); goto out; }
+        {   /* TX cell masks: bins = [NB][4] axes then [NB][2] (cos, sin) */
+            uint8_t *db = (uint8_t *)d_tmp + b_ptri + b_apex;
+            if ((e = hrt_hip_h2d(db, bins, b_bins))) { rc = hrt_fail_hip(e, "hipMemcpy(patch build)"); goto out; }
+            if ((e = hrt_hip_txcell_build(p->d_tri, T, (const float *)((uint8_t *)d_tmp + b_ptri) + 3 * (size_t)n_rx, n_tx, (const float *)db,
+                                          (const float *)(db + (uint64_t)HRT_RXT_BINS * 16), (unsigned long long *)(q + b_pdef + b_mask), NULL))) {
+                rc = hrt_fail_hip(e, "hrt_txcell_build_kernel"); goto out;
+            }
+        }
         if ((e = hrt_hip_stream_sync(NULL))) { rc = hrt_fail_hip(e, "hipStreamSynchronize"); goto out; }
+        p->kpatch.txcell = (const unsigned long long *)(q + b_pdef + b_mask);
         p->kpatch.mask = (const unsigned long long *)(q + b_pdef);
         p->kpatch.pdef = (const float *)q;
         p->kpatch.num_patch = (uint32_t)npatch;

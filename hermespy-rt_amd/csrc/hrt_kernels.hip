@@ -853,6 +853,26 @@ __device__ __forceinline__ Hit closest_hit_patch(TriPtr tri, OrigPtr orig, const
     return closest_hit_words(tri, orig, w, num_tri, o, d, valid, lane, kind);
 }
 
+// launch 0 on patch-table problems: the ray leaves TX `tx` exactly (o == its position), so its candidates are the
+// mask of the cube-map cell of its own direction (hrt_kpatch.txcell); the wave ORs and walks the union
+template <typename TriPtr, typename OrigPtr>
+__device__ __forceinline__ Hit closest_hit_txcell(TriPtr tri, OrigPtr orig, const hrt_kpatch &X, uint32_t tx, uint32_t num_tri,
+                                                  F3 o, F3 d, bool valid, uint32_t lane)
+{
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 0u;
+    if (valid) {
+        const Rsrc mr = make_rsrc(reinterpret_cast<const uint8_t *>(X.txcell));
+        const uint32_t off = (tx * HRT_RXT_BINS + rxt_cell(d)) * (HRT_PATCH_WORDS * 8u);
+        const auto a = __builtin_amdgcn_raw_buffer_load_b128(mr, (int)off, 0, 0);
+        const auto b = __builtin_amdgcn_raw_buffer_load_b128(mr, (int)(off + 16u), 0, 0);
+        w[0] = (uint32_t)a[0]; w[1] = (uint32_t)a[1]; w[2] = (uint32_t)a[2]; w[3] = (uint32_t)a[3];
+        w[4] = (uint32_t)b[0]; w[5] = (uint32_t)b[1]; w[6] = (uint32_t)b[2]; w[7] = (uint32_t)b[3];
+    }
+    return closest_hit_words(tri, orig, w, num_tri, o, d, valid, lane, 0);
+}
+
 template <bool MULTI, typename TriPtr>
 __device__ __forceinline__ Hit closest_hit_packet(TriPtr tri, const uint32_t *__restrict__ orig,
                                                   const hrt_krxt &X, uint32_t rxk,
@@ -3244,6 +3264,8 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
             const F3 ok = FIRST ? tx_origin(k) : o[k];
             if (FIRST && masked) {
                 h[k] = closest_hit_masked(tri, P.acc.orig, P.rxt, P.num_rx + htri[k], T, ok, d[k], valid[k], lane, 0);
+            } else if (FIRST && VARIANT == 2 && P.patch.txcell != nullptr) {
+                if constexpr (FIRST && VARIANT == 2) h[k] = closest_hit_txcell(tri, P.acc.orig, P.patch, htri[k], T, ok, d[k], valid[k], lane);
             } else {
                 Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
                 if constexpr (VARIANT >= 2 && VARIANT != 6) ball = origin_ball(ok, valid[k]);
@@ -3701,6 +3723,33 @@ __global__ __launch_bounds__(64) void hrt_rxt_build_kernel(const float *tri_f, u
                                  tri[HRT_ROW * j + 3], tri[HRT_ROW * j + 4]);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
         if (lane == 0) masks[((uint64_t)rx * HRT_RXT_BINS + cell) * W + r] = m;
+    }
+}
+
+// Builder of the TX cell masks (hrt_kpatch.txcell): one wave per (TX, cube-map cell); the packet = lines through the TX
+// (origin = the TX itself: launch rays start there exactly) with directions in the cell's cone.
+__global__ __launch_bounds__(64) void hrt_txcell_build_kernel(const float *tri_f, uint32_t num_tri, const float *tx_pos,
+                                                              const float *bin_dir4, const float *bin_cs2, unsigned long long *masks)
+{
+    const float4 *tri = reinterpret_cast<const float4 *>(tri_f);
+    const uint32_t cell = blockIdx.x, tx = blockIdx.y, lane = threadIdx.x;
+    Packet P;
+    P.oc = {tx_pos[3 * tx], tx_pos[3 * tx + 1], tx_pos[3 * tx + 2]};
+    P.bc = P.oc;
+    P.ro = 4e-6f * ((fabsf(P.oc.x) + fabsf(P.oc.y)) + fabsf(P.oc.z)) + 4e-6f;   // (rounding of anything formed from the TX)
+    P.br = P.ro;
+    P.ax = {bin_dir4[4 * cell], bin_dir4[4 * cell + 1], bin_dir4[4 * cell + 2]};
+    P.cosa = bin_cs2[2 * cell];
+    P.sina = bin_cs2[2 * cell + 1];
+    P.usable = true;
+    for (uint32_t r = 0; r < HRT_PATCH_WORDS; ++r) {
+        const uint32_t j = r * 64u + lane;
+        bool cand = false;
+        if (j < num_tri)
+            cand = !packet_culls(P, tri[HRT_ROW * j], tri[HRT_ROW * j + 1], tri[HRT_ROW * j + 2], tri[HRT_ROW * j + 3],
+                                 tri[HRT_ROW * j + 4]);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+        if (lane == 0) masks[((uint64_t)tx * HRT_RXT_BINS + cell) * HRT_PATCH_WORDS + r] = m;
     }
 }
 
@@ -4496,6 +4545,15 @@ int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_po
 {
     hipLaunchKernelGGL(hrt_rxt_build_kernel, dim3(HRT_RXT_BINS, num_rx), dim3(64), 0, (hipStream_t)stream,
                        d_tri, num_tri, d_rx_pos, d_bin_dir4, d_bin_cs2, d_ro_bin, cx, cy, cz, region_r, d_masks);
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_txcell_build(const float *d_tri, uint32_t num_tri, const float *d_tx_pos, uint32_t num_tx, const float *d_bin_dir4,
+                         const float *d_bin_cs2, unsigned long long *d_masks, void *stream)
+{
+    if (num_tx == 0 || num_tx > 65535u) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(hrt_txcell_build_kernel, dim3(HRT_RXT_BINS, num_tx), dim3(64), 0, (hipStream_t)stream, d_tri, num_tri,
+                       d_tx_pos, d_bin_dir4, d_bin_cs2, d_masks);
     return (int)hipGetLastError();
 }
 

@@ -121,6 +121,11 @@ typedef struct {
 typedef struct {
     const unsigned long long *mask; /* [num_apex][num_patch][HRT_PATCH_WORDS], or NULL (no tables) */
     const float *pdef;              /* [T][8]: g1 * nu (xyz), bits(base) | g2 * nv (xyz), bits(nu | nv << 16) */
+    const unsigned long long *txcell; /* [num_tx][HRT_RXT_BINS][HRT_PATCH_WORDS]: the launch rays leave a TX exactly, so the
+                                     * candidates of a ray are a function of the cube-map cell of its direction (built for
+                                     * origin = the TX, lines through it, the cell's cone): launch 0 by per-lane lookups
+                                     * too -- 2.4 candidates per wave on C3 against 1.9 of the packet test, without its
+                                     * ball, cone and culling round; or NULL */
     uint32_t num_patch;
     uint32_t num_img;               /* image-apex tables present for this many TXs (0 or num_tx) */
     float hmax;                     /* served origins lie within this distance of their triangle's plane */
@@ -251,6 +256,8 @@ int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint3
 int hrt_hip_rxt_build(const float *d_tri, uint32_t num_tri, const float *d_rx_pos, uint32_t num_rx,
                       const float *d_bin_dir4, const float *d_bin_cs2, const float *d_ro_bin,
                       float cx, float cy, float cz, float region_r, unsigned long long *d_masks, void *stream);
+int hrt_hip_txcell_build(const float *d_tri, uint32_t num_tri, const float *d_tx_pos, uint32_t num_tx, const float *d_bin_dir4,
+                         const float *d_bin_cs2, unsigned long long *d_masks, void *stream);
 int hrt_hip_patch_build(const float *d_tri, uint32_t num_tri, const float *d_pdef, const uint32_t *d_patch_tri,
                         uint32_t num_patch, const float *d_apex, uint32_t num_rx, uint32_t num_img, float hball,
                         float ro_rx, float ro_img, unsigned long long *d_masks, void *stream);

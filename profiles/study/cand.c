@@ -8,7 +8,9 @@
 #include <string.h>
 
 #define ROWF 20
+#ifndef RXT_N
 #define RXT_N 48
+#endif
 #define EPS 1.1920928955078125e-07f
 
 typedef struct { float oc[3], ro, bc[3], br, ax[3], cosa, sina; int usable; } Packet;
