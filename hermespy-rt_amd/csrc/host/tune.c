@@ -23,6 +23,7 @@ void hrt_tune_defaults(hrt_tune *t)
     t->k.los_big_min_tri = 16384;   /* LoS pass sliced over 256 waves per pair from here on (100 k triangles: 0.8 -> 0.05 ms) */
     t->k.fuse_staged_max_tri = 6;   /* fused launches: the staged walk over all rows up to here (a culling round costs more) */
     t->k.shade_global_normals = 0;
+    t->k.lb_max_polls = 8000;       /* ~10 ms; the wait is microseconds when the kernel owns the GPU (hrt_kernels.hip: lb_exclusive) */
     t->wide_cos = 0.0;              /* 0: HRT_WIDE_COS / HRT_WIDE_COS_BIG by table size (hrt_kparams.h holds the measurements) */
     t->wide_cap = -1;
     t->sort_rays = -1;              /* -1: tables beyond HRT_SORT_MIN_TRI */
@@ -61,6 +62,7 @@ int hrt_tune_load(hrt_tune *t)
         else if KEY("los_big_min_tri") t->k.los_big_min_tri = (uint32_t)u;
         else if KEY("fuse_staged_max_tri") t->k.fuse_staged_max_tri = (uint32_t)u;
         else if KEY("shade_global_normals") t->k.shade_global_normals = (uint32_t)u;
+        else if KEY("lb_max_polls") t->k.lb_max_polls = (uint32_t)u;
         else if KEY("wide_cos") t->wide_cos = v;
         else if KEY("wide_cap") t->wide_cap = (int64_t)strtoll(val, NULL, 10);
         else if KEY("sort_rays") t->sort_rays = (int)v;

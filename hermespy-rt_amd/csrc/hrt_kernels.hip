@@ -2449,7 +2449,17 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
         float theta = 0.f, fs0 = 0.f, tau = 0.f;
         F3 o = {0.f, 0.f, 0.f}, d = {0.f, 0.f, 1.f};
         float a0 = 1.f, a1 = 0.f, a2 = 1.f, a3 = 0.f;
-        if (valid) {
+        // the bounce's own trace result: requested in front of the records' stores.  (Bounce only -- the records are
+        // hrt_records_kernel's --: the state of an entry is only loaded if it hit: 40-55 % of the entries of C3 did
+        // not, and the kernel is bound by its traffic.)
+        uint32_t ptri = HRT_NO_HIT;
+        float pt = 0.f;
+        if (do_trace && valid) {
+            ptri = ldu(res_blk(P, P.num_rx), 0u, i4);
+            pt = ldf(res_blk(P, P.num_rx), cap4, i4);
+        }
+        const bool need_state = valid && !(P.records_done && ptri == HRT_NO_HIT);
+        if (need_state) {
             if (first) {
                 // src/compute_paths.c:452-466 + the launch Doppler term :494-500
                 uint32_t tx;
@@ -2472,14 +2482,6 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
                 a3 = ldf(hit_blk(P, pb), H_A3 * cap4, i4);
                 tau = ldf(hit_blk(P, pb), H_TAU * cap4, i4);
             }
-        }
-
-        // the bounce's own trace result: requested in front of the records' stores
-        uint32_t ptri = HRT_NO_HIT;
-        float pt = 0.f;
-        if (do_trace && valid) {
-            ptri = ldu(res_blk(P, P.num_rx), 0u, i4);
-            pt = ldf(res_blk(P, P.num_rx), cap4, i4);
         }
 
         // ---- scatter records of bounce b-1 (unless hrt_records_kernel wrote them) ----
@@ -2919,7 +2921,7 @@ __device__ __forceinline__ LbWords lb_words(const hrt_kparams &P, uint32_t b)
 // Exclusive prefix of `chunk` (survivors of all earlier chunks); c = the chunk's own count (already
 // published in its word).  Called by all 64 lanes of ONE wave (uniform control flow); the result is
 // wave-uniform.
-// Bounded: the chunks in front are waited for at most HRT_LB_MAX_POLLS polls (about 10 ms; the wait is
+// Bounded: the chunks in front are waited for at most `max_polls` polls (hrt_ktune.lb_max_polls: about 10 ms; the wait is
 // microseconds when the kernel owns the GPU).  A chunk only ever waits for lower-numbered chunks, and those have
 // been dispatched -- per XCD: the XCDs dispatch their shares of a grid independently, so a resident workgroup can
 // spin on one that still waits for a slot on another XCD.  Alone on the GPU that slot comes; when several fused
@@ -2931,11 +2933,8 @@ __device__ __forceinline__ LbWords lb_words(const hrt_kparams &P, uint32_t b)
 // per launch and keeps fusion off from then on.  (Tickets drawn at workgroup start make the order exact, but a
 // returning atomic on one address per workgroup cost 10 % of C4's step and 30 % of C2's: profiles/HISTORY.md r4.)
 constexpr uint32_t kLbAbort = 0xffffffffu;
-#ifndef HRT_LB_MAX_POLLS
-#define HRT_LB_MAX_POLLS 8000u   /* ~10 ms of polling */
-#endif
 __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chunk, uint32_t c, uint32_t lane,
-                                                 uint32_t *err_word, uint32_t *host_flag)
+                                                 uint32_t *err_word, uint32_t *host_flag, const uint32_t max_polls)
 {
     uint32_t polls = 0u;
     const uint32_t g = chunk >> 6, sg = chunk >> 12;
@@ -2965,7 +2964,7 @@ __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chun
         }
         if (ok_c && ok_g && ok_s) return sum_c + sum_g + wave_sum_u32((s0 & ~kLbDone) + (s1 & ~kLbDone));
         if (lb_load(err_word) & kErrFuseTimeout) return kLbAbort;        // somebody gave up: the launch is void
-        if (++polls > HRT_LB_MAX_POLLS) {
+        if (++polls > max_polls) {
             if (lane == 0) {
                 atomicOr(err_word, kErrFuseTimeout);
                 if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3388,7 +3387,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WA
         const bool need_prefix = c_total != 0u || (chunk & 63u) == 63u || chunk + 1u == n_chunks;
         if (need_prefix) {   // (uniform over the workgroup)
             if (tid < 64u) {   // wave 0
-                const uint32_t excl = lb_exclusive(W, chunk, c_total, lane, &counts[P.num_bounces + 1], P.host_flag);
+                const uint32_t excl = lb_exclusive(W, chunk, c_total, lane, &counts[P.num_bounces + 1], P.host_flag, P.tune.lb_max_polls);
                 if (lane == 0) {
                     L.wcnt[8] = excl;
                     if (excl != kLbAbort && chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length

@@ -157,6 +157,7 @@ typedef struct {
     uint64_t lds_tri_bytes_max;    /* tables up to this many bytes are staged in LDS */
     uint32_t trace_grid, shade_grid, wide_grid;
     uint32_t los_big_min_tri, fuse_staged_max_tri, shade_global_normals;
+    uint32_t lb_max_polls;         /* fused launches: polls of the prefix words before the step is declared void (~10 ms) */
 } hrt_ktune;
 #define HRT_TRACE_VARIANT_DEFAULT 7
 

@@ -74,3 +74,9 @@ def test_path_list_entry_validates_too(product_lib, scene):
     assert call(sc=None) == -1 and b"NULL" in product_lib.hrt_last_error()
     product_lib.hrt_path_list_free(C.byref(pl))      # freeing an empty list is fine
     product_lib.hrt_path_list_free(None)
+
+
+def test_unknown_tune_key_is_refused(product_lib, scene, monkeypatch):
+    """HRT_TUNE carries the developer switches; a key the library does not know is an error, not ignored"""
+    monkeypatch.setenv("HRT_TUNE", "variant=2,no_such_switch=1")
+    assert _call(product_lib, scene) == -1 and b"HRT_TUNE" in product_lib.hrt_last_error()
