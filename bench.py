@@ -336,7 +336,7 @@ def main():
     # rocprofv3 passes) for exactly this workload at N = 1, committed in profiles/.  The JSON carries
     # the hash of the kernel source it was measured on: `traffic_stale` says whether that is still
     # the source of this run.
-    kern_sha = hashlib.sha256(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", "hrt_kernels.hip"), "rb").read()).hexdigest()[:16]
+    kern_sha = hashlib.sha256(b"".join(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", f), "rb").read() for f in ("hrt_kernels.hip", "hrt_fused_body.inc"))).hexdigest()[:16]
     traffic, traffic_src, traffic_stale = None, None, None
     try:
         pj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))

@@ -486,10 +486,10 @@ static int run_batch(dev_ctx *c, uint32_t g)
         if ((rc = hrt_trace(prob, &s, (const float *)w->d_dirs, (const uint32_t *)w->d_order, w->d_ws, L.total_bytes, NULL, NULL))) goto done;
         if ((rc = hrt_device_sync(w->device, NULL))) goto done;
         DL(w->h_counts, L.off_counts, (nb + 2) * 4);
-        /* a fused launch gave up waiting (the GPU is shared with other fused kernels: hrt_kernels.hip,
-         * lb_exclusive): the step is void -- once more, two kernels per launch, and so from now on */
-        if (!(w->h_counts[nb + 1] & HRT_ERR_FUSE_TIMEOUT) || attempt) break;
-        hrt_fuse_disable();
+        /* a fused launch / the chain kernel gave up waiting (the GPU is shared with other such kernels:
+         * hrt_kernels.hip, lb_exclusive, hrt_chain_kernel): the step is void -- once more with that switched off
+         * (chain -> a kernel per launch -> two kernels per launch), and so from now on */
+        if (!(w->h_counts[nb + 1] & HRT_ERR_VOID) || attempt >= 2 || !hrt_void_step_retry(w->h_counts[nb + 1])) break;
     }
     c->t_dev += hrt_now_s() - t0;
 

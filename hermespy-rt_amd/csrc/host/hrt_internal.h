@@ -43,6 +43,8 @@ typedef struct {
     uint64_t accel_big, accel_fine_min;   /* accel_fine_min UINT64_MAX: HRT_FINE_MIN_TRI */
     int accel_fine;              /* -1: auto, 0: never */
     int no_bounce_prefetch, no_scatter;
+    int no_chain;                  /* launches 1 .. nb one by one instead of hrt_chain_kernel */
+    int chain_from;                /* first launch of the chain kernel (default 1) */
 } hrt_tune;
 void hrt_tune_defaults(hrt_tune *t);
 int hrt_tune_load(hrt_tune *t);
@@ -91,7 +93,7 @@ struct hrt_problem {
     void *d_rxt;                 /* per-RX direction tables (device blob), or NULL */
     hrt_krxt krxt;
     uint64_t rxt_entries;        /* total list entries over all (rx, cell) */
-    uint32_t *h_fuse_flag, *d_fuse_flag;   /* pinned word a fused launch sets when it gives up (hrt_kparams.host_flag) */
+    uint32_t *h_fuse_flag, *d_fuse_flag;   /* pinned words a fused launch / the chain kernel sets when it gives up (hrt_kparams.host_flag) */
     void *aux_stream;            /* second stream of a trace: the records kernels run beside the bounce kernels */
     void *aux_ev[2];             /* fork (live list complete) / join (records done): ordering-only events */
     void *d_patch;               /* patch tables (device blob), or NULL */
@@ -120,6 +122,9 @@ double hrt_now_s(void);
  * kernels); hrt_trace looks at it, and at the problem's pinned flag word, before every trace */
 void hrt_fuse_disable(void);
 int hrt_fuse_disabled(void);
+void hrt_chain_disable(void);
+int hrt_chain_disabled(void);
+int hrt_void_step_retry(uint32_t err_word);
 
 /* ---- buffers of one device worker of the drop-in calls (compute_paths.c), pooled between calls ---- */
 typedef struct {

@@ -233,8 +233,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             if ((rc = hrt_device_sync(device, NULL))) goto done;
             DLP(h_counts, L.off_counts, (nb + 2) * 4);
             /* (a fused launch timed out on a shared GPU: the step is void, once more unfused -- compute_paths.c) */
-            if (!(h_counts[nb + 1] & HRT_ERR_FUSE_TIMEOUT) || attempt) break;
-            hrt_fuse_disable();
+            if (!(h_counts[nb + 1] & HRT_ERR_VOID) || attempt >= 2 || !hrt_void_step_retry(h_counts[nb + 1])) break;
         }
         t_dev += hrt_now_s() - t0;
 

@@ -606,7 +606,7 @@ int hrt_problem_create_for(const Scene *scene, const Vec3 *rx_pos, const Vec3 *t
         if (hrt_hip_host_malloc_mapped(&hf, &df, 64) == 0) {
             p->h_fuse_flag = (uint32_t *)hf;
             p->d_fuse_flag = (uint32_t *)df;
-            *p->h_fuse_flag = 0u;
+            p->h_fuse_flag[0] = p->h_fuse_flag[1] = 0u;
         }
     }
     uint8_t *b = (uint8_t *)p->d_blob;
@@ -1140,14 +1140,25 @@ int hrt_trace_flags(const hrt_problem *p, const hrt_shard *s, const float *d_dir
  * on tables of at most HRT_FUSE_MAX_TRI triangles (one culling round: there the split into a
  * geometry kernel and a shading kernel only costs traffic and launches); 0 = never (two kernels per
  * launch); 1 = launch 0 only; 2 = every launch, on any table of one culling block (<= 1024). */
-static int g_fuse_off;   /* (an int written once: benign if two threads race to set it) */
+static int g_fuse_off, g_chain_off;   /* (ints written once: benign if two threads race to set them) */
 void hrt_fuse_disable(void) { g_fuse_off = 1; }
 int hrt_fuse_disabled(void) { return g_fuse_off; }
+void hrt_chain_disable(void) { g_chain_off = 1; }
+int hrt_chain_disabled(void) { return g_chain_off; }
+/* what the host does about a void step (error word of its counts): 1 = run it again (something was switched off) */
+int hrt_void_step_retry(uint32_t err_word)
+{
+    int again = 0;
+    if ((err_word & HRT_ERR_CHAIN_TIMEOUT) && !g_chain_off) { g_chain_off = 1; again = 1; }
+    if ((err_word & HRT_ERR_FUSE_TIMEOUT) && !g_fuse_off) { g_fuse_off = 1; again = 1; }
+    return again;
+}
 
 static uint32_t fuse_mode(const hrt_problem *p)
 {
     /* a fused launch of this process gave up waiting once: the GPU is shared with other fused kernels */
-    if (p->h_fuse_flag && *(volatile uint32_t *)p->h_fuse_flag) g_fuse_off = 1;
+    if (p->h_fuse_flag && ((volatile uint32_t *)p->h_fuse_flag)[0]) g_fuse_off = 1;
+    if (p->h_fuse_flag && ((volatile uint32_t *)p->h_fuse_flag)[1]) g_chain_off = 1;
     if (g_fuse_off) return 0u;
     const char *v = getenv("HRT_FUSE");
     const int one_block = p->num_tri <= 1024u;
@@ -1294,6 +1305,22 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
          * stream, beside the bounce's own kernels (a VALU-bound kernel beside latency-bound ones), forked and
          * joined by events.  With a timer everything stays on one stream, so that the per-kernel times mean
          * what they say. */
+        /* Tables on which whole bounces are fused: the TAIL -- launches 2 .. nb -- as ONE persistent kernel
+         * (hrt_chain_kernel: a grid barrier instead of a launch per bounce, and it ends with the first empty
+         * list).  Measured on C4 (profiles/HISTORY.md r4): an empty launch costs 3 us + the dispatch of a grid
+         * sized for the worst case (7 us for C4's 31 250 workgroups), a launch with a few thousand entries 15-20 us
+         * (a workgroup's latency chain); a bounce inside the chain costs about the same as such a launch, its
+         * roll call 6 us -- so the chain pays from three or four launches on (C4, 6 bounces: 0.629 -> 0.607 ms;
+         * 12 bounces: 0.697 -> 0.613), not before (3 bounces: 0.595 -> 0.602), and launch 1, a LONG list, stays
+         * its own kernel (in the chain's static deal of chunks it took 13 % longer).  With a timer every launch
+         * keeps its own kernel.  tune: no_chain, chain_from (first launch of the chain; set: no minimum depth) */
+        const uint32_t chain_b0 = p->tune.chain_from >= 1 ? (uint32_t)p->tune.chain_from : 2u;
+        if (b == chain_b0 && (p->tune.chain_from >= 1 || nb >= 4u) && (K.fuse & HRT_FUSE_BOUNCES) && !ev && !p->sort_rays &&
+            !p->tune.no_chain && !g_chain_off && !hip) {
+            const int cr = hrt_hip_launch_chain(&K, b, stream);   /* -1: not on this problem */
+            if (cr > 0) hip = cr;
+            if (cr >= 0) break;
+        }
         int own_records = 0;
         if (b >= 1 && !hip) {
             void *rs = stream;

@@ -81,6 +81,8 @@ int hrt_tune_load(hrt_tune *t)
         else if KEY("accel_fine_min") t->accel_fine_min = u;
         else if KEY("no_bounce_prefetch") t->no_bounce_prefetch = (int)v;
         else if KEY("no_scatter") t->no_scatter = (int)v;
+        else if KEY("no_chain") t->no_chain = (int)v;
+        else if KEY("chain_from") t->chain_from = (int)v;
         else rc = hrt_fail(HRT_E_INVALID, "HRT_TUNE: unknown key '%s'", tok);
 #undef KEY
     }

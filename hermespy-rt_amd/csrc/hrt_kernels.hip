@@ -58,6 +58,8 @@ constexpr float kOnePlusEps = 1.00000011920928955078125f;   // next float after 
 constexpr float kPi = 3.14159265358979323846f;              // src/compute_paths.c:18 (float)
 constexpr float kC = 299792458.0f;                          // src/compute_paths.c:19
 constexpr uint32_t kErrFuseTimeout = HRT_ERR_FUSE_TIMEOUT;   // bit of the trace's error word (counts[nb + 1]): see lb_exclusive
+constexpr uint32_t kErrChainTimeout = HRT_ERR_CHAIN_TIMEOUT;   // ... the same from hrt_chain_kernel (its grid was not resident)
+constexpr uint32_t kErrVoid = kErrFuseTimeout | kErrChainTimeout;   // either: the step is void, every kernel of it returns at once
 
 struct F3 { float x, y, z; };
 
@@ -1719,6 +1721,24 @@ __device__ __forceinline__ void stu(Rsrc r, uint32_t field_off, uint32_t byte_of
 {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, (int)field_off, 0);
 }
+// The same with a cache policy (AUX 16 = sc1: agent scope -- the access goes through the XCD's L2 to memory.
+// hrt_chain_kernel hands a bounce's survivors to workgroups on other XCDs INSIDE one kernel this way: no fence,
+// no L2 write-back)
+template <int AUX>
+__device__ __forceinline__ float ldf_x(Rsrc r, uint32_t field_off, uint32_t byte_off)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)field_off, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ uint32_t ldu_x(Rsrc r, uint32_t field_off, uint32_t byte_off)
+{
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)field_off, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void stf_x(Rsrc r, uint32_t field_off, uint32_t byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)field_off, AUX);
+}
 // per-lane gathers from the triangle / mesh tables (shade kernel): row j, byte `at` inside the row
 __device__ __forceinline__ F3 gather3(Rsrc r, uint32_t row_bytes, uint32_t j, uint32_t at)
 {
@@ -1838,7 +1858,7 @@ __global__ __launch_bounds__(HRT_BLOCK, (VARIANT == 2 ? HRT_TRACE_WAVES_V2 : (VA
     const uint32_t tid = threadIdx.x;
     const bool first = (b == 0);
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
+    if (counts[P.num_bounces + 1] & kErrVoid) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = first ? P.n0 : counts[b];
     const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
     // unit types of this launch: the shadow rays (b >= 1), one type per RX (k = rx) -- with patch tables
@@ -2393,7 +2413,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_SHADE_WAVES) void hrt_shade_kernel(c
     const bool first = (b == 0);
     const bool do_trace = (b < P.num_bounces);
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
+    if (counts[P.num_bounces + 1] & kErrVoid) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = first ? P.n0 : counts[b];
     if ((uint64_t)blockIdx.x * HRT_BLOCK >= n_in) return;
 
@@ -2685,7 +2705,7 @@ __global__ __launch_bounds__(HRT_BLOCK, 8) void hrt_image_kernel(const hrt_kpara
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
+    if (counts[P.num_bounces + 1] & kErrVoid) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = counts[b];
     const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
     if (blockIdx.x >= n_chunks) return;
@@ -2745,7 +2765,7 @@ __global__ __launch_bounds__(HRT_BLOCK, HRT_RECORDS_WAVES) void hrt_records_kern
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(P.ws + P.off_counts);
-    if (counts[P.num_bounces + 1] & kErrFuseTimeout) return;   // a fused launch of this trace timed out: the host redoes the step
+    if (counts[P.num_bounces + 1] & kErrVoid) return;   // a fused launch of this trace timed out: the host redoes the step
     const uint32_t n_in = counts[b];
     const uint32_t n_chunks = (n_in + HRT_BLOCK - 1) / HRT_BLOCK;
     if (blockIdx.x >= n_chunks) return;
@@ -2933,8 +2953,17 @@ __device__ __forceinline__ LbWords lb_words(const hrt_kparams &P, uint32_t b)
 // per launch and keeps fusion off from then on.  (Tickets drawn at workgroup start make the order exact, but a
 // returning atomic on one address per workgroup cost 10 % of C4's step and 30 % of C2's: profiles/HISTORY.md r4.)
 constexpr uint32_t kLbAbort = 0xffffffffu;
+// the step is void: the bit in the trace's error word, and the host's flag word of that kind (host_flag[0]: a
+// fused launch, [1]: the chain kernel) -- pinned memory, seen by the host without synchronising
+__device__ __forceinline__ void give_up(uint32_t *err_word, uint32_t *host_flag, uint32_t err_bit)
+{
+    atomicOr(err_word, err_bit);
+    if (host_flag)
+        __hip_atomic_store(host_flag + (err_bit == kErrChainTimeout ? 1 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chunk, uint32_t c, uint32_t lane,
-                                                 uint32_t *err_word, uint32_t *host_flag, const uint32_t max_polls)
+                                                 uint32_t *err_word, uint32_t *host_flag, const uint32_t max_polls,
+                                                 const uint32_t err_bit = kErrFuseTimeout)
 {
     uint32_t polls = 0u;
     const uint32_t g = chunk >> 6, sg = chunk >> 12;
@@ -2963,12 +2992,9 @@ __device__ __forceinline__ uint32_t lb_exclusive(const LbWords &W, uint32_t chun
             s_owed = false;
         }
         if (ok_c && ok_g && ok_s) return sum_c + sum_g + wave_sum_u32((s0 & ~kLbDone) + (s1 & ~kLbDone));
-        if (lb_load(err_word) & kErrFuseTimeout) return kLbAbort;        // somebody gave up: the launch is void
+        if (lb_load(err_word) & kErrVoid) return kLbAbort;        // somebody gave up: the launch is void
         if (++polls > max_polls) {
-            if (lane == 0) {
-                atomicOr(err_word, kErrFuseTimeout);
-                if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            if (lane == 0) give_up(err_word, host_flag, err_bit);
             return kLbAbort;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -3042,25 +3068,26 @@ __device__ __forceinline__ void bounce_apply(const float4 *l_mat, float fsl_mult
     o = add3(o, mul3(d, 1e-4f));
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ void store_survivor(Rsrc out, uint32_t cap4, uint32_t k4, uint32_t ray, uint32_t ntri,
                                                float nth, float fs0, F3 o, F3 d, float a0, float a1, float a2,
                                                float a3, float tau)
 {
-    stf(out, H_RAY * cap4, k4, __uint_as_float(ray));
-    stf(out, H_TRI * cap4, k4, __uint_as_float(ntri));
-    stf(out, H_THETA * cap4, k4, nth);
-    stf(out, H_FS0 * cap4, k4, fs0);
-    stf(out, H_OX * cap4, k4, o.x);
-    stf(out, H_OY * cap4, k4, o.y);
-    stf(out, H_OZ * cap4, k4, o.z);
-    stf(out, H_DX * cap4, k4, d.x);
-    stf(out, H_DY * cap4, k4, d.y);
-    stf(out, H_DZ * cap4, k4, d.z);
-    stf(out, H_A0 * cap4, k4, a0);
-    stf(out, H_A1 * cap4, k4, a1);
-    stf(out, H_A2 * cap4, k4, a2);
-    stf(out, H_A3 * cap4, k4, a3);
-    stf(out, H_TAU * cap4, k4, tau);
+    stf_x<AUX>(out, H_RAY * cap4, k4, __uint_as_float(ray));
+    stf_x<AUX>(out, H_TRI * cap4, k4, __uint_as_float(ntri));
+    stf_x<AUX>(out, H_THETA * cap4, k4, nth);
+    stf_x<AUX>(out, H_FS0 * cap4, k4, fs0);
+    stf_x<AUX>(out, H_OX * cap4, k4, o.x);
+    stf_x<AUX>(out, H_OY * cap4, k4, o.y);
+    stf_x<AUX>(out, H_OZ * cap4, k4, o.z);
+    stf_x<AUX>(out, H_DX * cap4, k4, d.x);
+    stf_x<AUX>(out, H_DY * cap4, k4, d.y);
+    stf_x<AUX>(out, H_DZ * cap4, k4, d.z);
+    stf_x<AUX>(out, H_A0 * cap4, k4, a0);
+    stf_x<AUX>(out, H_A1 * cap4, k4, a1);
+    stf_x<AUX>(out, H_A2 * cap4, k4, a2);
+    stf_x<AUX>(out, H_A3 * cap4, k4, a3);
+    stf_x<AUX>(out, H_TAU * cap4, k4, tau);
 }
 
 constexpr uint32_t kShortList = 256u * 1024u;   // entries: one packet per wave fills the chip once
@@ -3088,349 +3115,132 @@ constexpr uint32_t kShortList = 256u * 1024u;   // entries: one packet per wave 
 // survivors, publish; (3) b >= 1: shadow traces + records of the K entries -- the chunks in front
 // publish meanwhile; (4) prefix of the macro-chunk; (5) Fresnel / reflection of the survivors and
 // their stores at (prefix + rank): sub-chunk-major, i.e. in entry order (stable).
+// One macro-chunk of launch b = csrc/hrt_fused_body.inc: the body of hrt_fused_kernel, and -- CHAIN -- of
+// hrt_chain_kernel's loops: there the tables are staged once per workgroup by the kernel, and the live list
+// travels between the bounces with sc1 accesses.
 template <bool TRI_IN_LDS, int VARIANT, bool FIRST, int K>
 __global__ __launch_bounds__(HRT_BLOCK, (FIRST ? HRT_FUSED_WAVES0 : HRT_FUSED_WAVESB)) void hrt_fused_kernel(const hrt_kparams P, const uint32_t b)
 {
     extern __shared__ float4 lds[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t *counts = reinterpret_cast<uint32_t *>(P.ws + P.off_counts);
-    if (FIRST && blockIdx.x >= gridDim.x - P.los_blocks) {   // the LoS pass rides along (src/compute_paths.c:515-577)
-        los_pairs(P, blockIdx.x - (gridDim.x - P.los_blocks));
-        return;
-    }
-    const uint32_t n_in = FIRST ? P.n0 : counts[b];
-    if (!FIRST && (counts[P.num_bounces + 1] & kErrFuseTimeout)) return;   // an earlier fused launch of this trace timed out
-    // A SHORT list is bound by the latency of one workgroup, not by throughput: then a workgroup takes
-    // one packet per wave (macro-chunk = 256 entries), which spreads the list over K times as many CUs
-    // (the grid covers ceil(cap / (256 K)) macro-chunks, so this needs n_in <= grid * 256).
-    const uint32_t n_grid = gridDim.x - (FIRST ? P.los_blocks : 0u);
-    const uint32_t Ke = (K > 1 && n_in <= kShortList && (uint64_t)n_grid * HRT_BLOCK >= n_in) ? 1u : (uint32_t)K;
-    const uint32_t MC = Ke * HRT_BLOCK;          // entries per macro-chunk
-    const uint32_t n_chunks = (n_in + MC - 1u) / MC;
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= n_chunks) return;
-    const bool do_trace = FIRST || (b < P.num_bounces);
+    constexpr bool CHAIN = false;
+    const uint32_t chunk_c = 0u, n_in_c = 0u, Ke_c = 0u, n_chunks_c = 0u;
+    const bool sc1_in = false;
+#include "hrt_fused_body.inc"
+}
 
-    const uint32_t T = P.num_tri;
-    const uint32_t cap4 = (uint32_t)P.cap * 4u;
-    const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
-    const float2 *g_tg = reinterpret_cast<const float2 *>(P.acc.tg);
-    const float4 *g_leaf = reinterpret_cast<const float4 *>(P.acc.leaf);
-    const uint32_t n_leaf = P.acc.num_leaf;
-    const FusedLds L = fused_lds<TRI_IN_LDS, (VARIANT == 9)>(lds, T, n_leaf, P.num_rx, wave);
-#ifdef HRT_PHASE_STATS
-    // (make EXTRA=-DHRT_PHASE_STATS) time stamps of a workgroup's life (thread 0, 100 MHz wall clock):
-    // g_phase[chunk] = {start, loads + staging done, traces + publish done, records done, prefix
-    // known, stores issued}; launch HRT_PHASE_BOUNCE only (hrt_hip_read_stats dumps them to HRT_PHASE_FILE)
-    int ph_i = 0;
-#define HRT_PHASE(col)                                                                           \
-    do {                                                                                         \
-        if (tid == 0 && b == P.phase_bounce && chunk < 65536u) g_phase[chunk][ph_i++] = wall_clock64(); \
-    } while (0)
-    HRT_PHASE(0);
-#else
-#define HRT_PHASE(col) do { } while (0)
-#endif
-
-    // ---- (1) ray state of the K entries: requested before the table staging, so that both are in flight ----
-    // (FIRST: htri[k] holds the entry's TX; origin and launch Doppler term are formed where they are
-    // used -- the origin from the TX positions in LDS -- instead of being held in registers)
-    uint32_t ray[K], htri[K];
-    float theta[K], fs0[K], tau[K], a0[K], a1[K], a2[K], a3[K];
-    F3 o[K], d[K];
-    bool valid[K];
-    // src/compute_paths.c:452-455: ray i of the launch set, lane i = the i-th ray of the coherent order
-    auto launch_entry = [&](int k) {
-        const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
-        const uint32_t tx = (P.num_tx == 1u) ? 0u : i / P.num_local;
-        const uint32_t pos = i - tx * P.num_local;
-        const uint32_t il = P.order ? P.order[pos] : pos;
-        ray[k] = tx * P.num_local + il;
-        htri[k] = tx;
-        const uint64_t row = P.dirs_in_launch_order ? pos : il;
-        d[k] = {P.dirs[3 * row], P.dirs[3 * row + 1], P.dirs[3 * row + 2]};
-    };
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
-        const uint32_t i4 = i * 4u;
-        valid[k] = (uint32_t)k < Ke && i < n_in;
-        ray[k] = 0u; htri[k] = 0u;
-        theta[k] = 0.f; fs0[k] = 0.f; tau[k] = 0.f;
-        a0[k] = 1.f; a1[k] = 0.f; a2[k] = 1.f; a3[k] = 0.f;
-        o[k] = {0.f, 0.f, 0.f};
-        d[k] = {0.f, 0.f, 1.f};
-        if (valid[k]) {
-            if (FIRST) {
-                launch_entry(k);
-            } else {
-                const Rsrc in = hit_blk(P, b - 1);
-                ray[k] = ldu(in, H_RAY * cap4, i4);
-                htri[k] = ldu(in, H_TRI * cap4, i4);
-                theta[k] = ldf(in, H_THETA * cap4, i4);
-                fs0[k] = ldf(in, H_FS0 * cap4, i4);
-                o[k] = {ldf(in, H_OX * cap4, i4), ldf(in, H_OY * cap4, i4), ldf(in, H_OZ * cap4, i4)};
-                d[k] = {ldf(in, H_DX * cap4, i4), ldf(in, H_DY * cap4, i4), ldf(in, H_DZ * cap4, i4)};
-                a0[k] = ldf(in, H_A0 * cap4, i4);
-                a1[k] = ldf(in, H_A1 * cap4, i4);
-                a2[k] = ldf(in, H_A2 * cap4, i4);
-                a3[k] = ldf(in, H_A3 * cap4, i4);
-                tau[k] = ldf(in, H_TAU * cap4, i4);
+// ===================================================================================
+// Launches b0 .. num_bounces as ONE kernel (tables on which whole bounces are fused): a persistent grid of G
+// workgroups -- G = what the chip holds at once, from the occupancy query: every workgroup is resident, so the
+// waits below are waits for running code -- loops over the bounces; inside a bounce workgroup j takes the
+// macro-chunks j, j + G, ... (ascending, so a chunk still only waits for chunks that are running or done), and
+// between two bounces stands a grid barrier (chain_barrier: flags, two round trips).  No fence: a bounce's
+// survivors are written and read with sc1 accesses (fused_chunk<CHAIN>), the
+// records -- which nobody reads in here -- stay ordinary stores.  The loop ends with the first empty live list.
+// What it saves is the fixed cost of a launch (~6 us) and of dispatching a grid sized for the worst case (the
+// host does not know the list's length: 31 250 empty workgroups = 8 us on C4), per bounce: C4's five tail
+// launches, all of a short step.  The waits are bounded like lb_exclusive's (shared GPU: void step, the host
+// falls back); with a timer every launch runs as its own kernel (hrt_fused_kernel), so per-launch times exist.
+// ===================================================================================
+// Grid barrier of hrt_chain_kernel: no atomics (1 024 returning adds on one word serialise at ~60 ns each: 61 us
+// per barrier, measured), no fence -- flags.  Workgroup j stores `tag` into word j; the first workgroup of every 64
+// waits (one load per lane) for its group's words and stores the group's word; everybody waits for the <= 64
+// group words: two round trips.  The words are launch (b - 1)'s status words (W): dead once every workgroup is past
+// that launch, and a tag (bit 30 set, bit 31 clear) is neither a fresh word (0) nor a status (bit 31 set).
+// All threads call it; false = the wait ran out (the grid is not resident: shared GPU) or somebody else gave up.
+constexpr uint32_t kChainTag = 1u << 30;
+constexpr uint32_t kChainMaxGrid = 4096u;
+__device__ __forceinline__ bool chain_barrier(const LbWords &W, const uint32_t tag, const uint32_t G, uint32_t *err_word,
+                                              uint32_t *host_flag, const uint32_t max_polls, uint32_t *lds_flag)
+{
+    __builtin_amdgcn_s_waitcnt(0);   // this thread's stores have left (vmcnt 0) ...
+    __syncthreads();                 // ... and so have the workgroup's
+    const uint32_t tid = threadIdx.x;
+    if (tid < 64u) {
+        const uint32_t j = blockIdx.x, lane = tid;
+        if (lane == 0) lb_store(W.chunk + j, tag);
+        uint32_t polls = 0u;
+        bool ok = true;
+        if ((j & 63u) == 0u) {   // the group's first workgroup collects the group
+            const bool want = j + lane < G;
+            for (;;) {
+                const uint32_t v = want ? lb_load(W.chunk + j + lane) : tag;
+                if (HRT_BALLOT(v != tag) == 0ull) break;
+                if (lb_load(err_word) & kErrVoid) { ok = false; break; }
+                if (++polls > max_polls) {
+                    if (lane == 0) give_up(err_word, host_flag, kErrChainTimeout);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (ok && lane == 0) lb_store(W.group + (j >> 6), tag);
+        }
+        if (ok) {
+            const bool want = lane < ((G + 63u) >> 6);
+            for (;;) {
+                const uint32_t v = want ? lb_load(W.group + lane) : tag;
+                if (HRT_BALLOT(v != tag) == 0ull) break;
+                if (lb_load(err_word) & kErrVoid) { ok = false; break; }
+                if (++polls > max_polls) {
+                    if (lane == 0) give_up(err_word, host_flag, kErrChainTimeout);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
         }
+        if (lane == 0) *lds_flag = ok ? 1u : 0u;
     }
-    // origin of launch ray k (FIRST)
-    auto tx_origin = [&](int k) -> F3 {
-        const uint32_t tx = htri[k];
-        if (tx < kLdsTx) {
-            const float4 q = L.tx[tx];
-            return {q.x, q.y, q.z};
-        }
-        return {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
-    };
+    __syncthreads();
+    return *lds_flag != 0u;
+}
 
-    if (TRI_IN_LDS) {
-        // (four loads in flight per thread: a load -> store -> load chain costs a round trip per 4 KB)
-        const uint32_t n4 = HRT_ROW * T;
-        for (uint32_t k0 = tid; k0 < n4; k0 += 4u * HRT_BLOCK) {
-            const uint32_t k1 = k0 + HRT_BLOCK, k2 = k0 + 2u * HRT_BLOCK, k3 = k0 + 3u * HRT_BLOCK;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 t0 = g_tri[k0], t1 = k1 < n4 ? g_tri[k1] : z, t2 = k2 < n4 ? g_tri[k2] : z,
-                         t3 = k3 < n4 ? g_tri[k3] : z;
-            L.tri[k0] = t0;
-            if (k1 < n4) L.tri[k1] = t1;
-            if (k2 < n4) L.tri[k2] = t2;
-            if (k3 < n4) L.tri[k3] = t3;
+template <bool TRI_IN_LDS, int VARIANT, int K>
+__global__ __launch_bounds__(HRT_BLOCK, HRT_FUSED_WAVESB) void hrt_chain_kernel(const hrt_kparams P, const uint32_t b0)
+{
+    extern __shared__ float4 lds[];
+    constexpr bool FIRST = false, CHAIN = true;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *counts = reinterpret_cast<uint32_t *>(P.ws + P.off_counts);
+    uint32_t *err_word = &counts[P.num_bounces + 1];
+    if (*err_word & kErrVoid) return;
+    const uint32_t G = gridDim.x;   // (<= kChainMaxGrid and <= lb_chunks: the shim)
+    const FusedLds L = fused_lds<TRI_IN_LDS, (VARIANT == 9)>(lds, P.num_tri, P.acc.num_leaf, P.num_rx, tid >> 6);
+    {   // the tables, once
+        const uint32_t T = P.num_tri, n_leaf = P.acc.num_leaf;
+        if (TRI_IN_LDS) {
+            const float4 *g_tri = reinterpret_cast<const float4 *>(P.tri);
+            for (uint32_t k = tid; k < HRT_ROW * T; k += HRT_BLOCK) L.tri[k] = g_tri[k];
+            if constexpr (VARIANT >= 4) {
+                const float2 *g_tg = reinterpret_cast<const float2 *>(P.acc.tg);
+                const float4 *g_leaf = reinterpret_cast<const float4 *>(P.acc.leaf);
+                for (uint32_t k = tid; k < T; k += HRT_BLOCK) L.tg[k] = g_tg[k];
+                for (uint32_t k = tid; k < 2u * n_leaf; k += HRT_BLOCK) L.leaf[k] = g_leaf[k];
+            }
         }
-        if constexpr (VARIANT >= 4) {
-            for (uint32_t k = tid; k < T; k += HRT_BLOCK) L.tg[k] = g_tg[k];
-            for (uint32_t k = tid; k < 2u * n_leaf; k += HRT_BLOCK) L.leaf[k] = g_leaf[k];
-        }
-    }
-    if (!FIRST)
         for (uint32_t k = tid; k < P.num_rx; k += HRT_BLOCK)
             L.rx[k] = make_float4(P.rx_pos[3 * k], P.rx_pos[3 * k + 1], P.rx_pos[3 * k + 2], 0.f);
-    else if (tid < min(P.num_tx, kLdsTx))
-        L.tx[tid] = make_float4(P.tx_pos[3 * tid], P.tx_pos[3 * tid + 1], P.tx_pos[3 * tid + 2], 0.f);
-    {
         const float4 *g_mat = reinterpret_cast<const float4 *>(P.mat);
         for (uint32_t k = tid; k < 4u * HRT_NUM_MATERIALS; k += HRT_BLOCK) L.mat[k] = g_mat[k];
     }
-    __syncthreads();
-    auto tri = [&]() {
-        if constexpr (TRI_IN_LDS) return (const float4 *)L.tri;
-        else return g_tri;
-    }();
-    auto tg = [&]() {
-        if constexpr (TRI_IN_LDS) return (const float2 *)L.tg;
-        else return g_tg;
-    }();
-    auto leaf = [&]() {
-        if constexpr (TRI_IN_LDS) return (const float4 *)L.leaf;
-        else return g_leaf;
-    }();
-    const Rsrc mesh_r = make_rsrc(reinterpret_cast<const uint8_t *>(P.mesh));
-    HRT_PHASE(9);
-
-    // (tables of <= 64 triangles: apex-bound traces go through the per-cell candidate masks)
-    const bool masked = VARIANT == 2 && P.rxt.cell_mask != nullptr;
-    // ---- (2) the bounce traces (src/compute_paths.c:615), survivors counted per (sub-chunk, wave) ----
-    Hit h[K];
-    unsigned long long hm[K];
-    const LbWords W = lb_words(P, b);
-    uint32_t c_total = 0u;
-    if (do_trace) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            F3 apex = {0.f, 0.f, 0.f};
-            uint32_t apex_k = P.num_rx;
-            if (FIRST && P.rxt.num_txt != 0u) {   // the TX's direction table serves the launch packet
-                uint32_t tx = 0u;
-                if (P.num_tx != 1u) {
-                    tx = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)((chunk * MC + (uint32_t)k * HRT_BLOCK + (tid & ~63u)) / P.num_local));
-                    tx = min(tx, P.num_tx - 1u);
-                }
-                apex = {P.tx_pos[3 * tx], P.tx_pos[3 * tx + 1], P.tx_pos[3 * tx + 2]};
-                apex_k = P.num_rx + tx;
-            }
-            if ((uint32_t)k >= Ke) {   // (short list: one packet per wave)
-                h[k] = {HRT_NO_HIT, 1e9f};
-                hm[k] = 0ull;
-                if (lane == 0) L.wcnt[16 + k * 4 + (int)wave] = 0u;
-                continue;
-            }
-            const F3 ok = FIRST ? tx_origin(k) : o[k];
-            if (FIRST && masked) {
-                h[k] = closest_hit_masked(tri, P.acc.orig, P.rxt, P.num_rx + htri[k], T, ok, d[k], valid[k], lane, 0);
-            } else if (FIRST && VARIANT == 2 && P.patch.txcell != nullptr) {
-                if constexpr (FIRST && VARIANT == 2) h[k] = closest_hit_txcell(tri, P.acc.orig, P.patch, htri[k], T, ok, d[k], valid[k], lane);
-            } else {
-                Ball ball = {{0.f, 0.f, 0.f}, 0.f, false};
-                if constexpr (VARIANT >= 2 && VARIANT != 6) ball = origin_ball(ok, valid[k]);
-                h[k] = closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, apex_k, P.acc.orig, T, ok, d[k], valid[k], lane,
-                                            ball, false, apex, L.mask, L.wleaf, FIRST ? 0 : 1);
-            }
-            hm[k] = HRT_BALLOT(valid[k] && h[k].tri != HRT_NO_HIT);
-            if (lane == 0) L.wcnt[16 + k * 4 + (int)wave] = (uint32_t)__popcll(hm[k]);
+    // Roll call before any work: is the whole grid resident?  Alone on the GPU it is within microseconds; when
+    // other kernels hold the slots (processes sharing the GPU, a long kernel on another stream) it may never be,
+    // and the answer should not take the 10 ms the waits inside the work are given: ~0.3 ms, then the step is
+    // void (HRT_ERR_CHAIN_TIMEOUT) and the host goes on with a kernel per launch.
+    const uint32_t roll_polls = P.tune.lb_max_polls < 256u ? P.tune.lb_max_polls : 256u;
+    if (!chain_barrier(lb_words(P, b0 - 1u), kChainTag | 0xffffu, G, err_word, P.host_flag, roll_polls, &L.wcnt[9])) return;
+    for (uint32_t b = b0; b <= P.num_bounces; ++b) {
+        const uint32_t n_in_c = (b == b0) ? counts[b] : lb_load(&counts[b]);   // (uniform over the grid)
+        if (n_in_c == 0u) return;
+        const uint32_t Ke_c = (K > 1 && n_in_c <= kShortList && (uint64_t)G * HRT_BLOCK >= n_in_c) ? 1u : (uint32_t)K;
+        const uint32_t n_chunks_c = (n_in_c + Ke_c * HRT_BLOCK - 1u) / (Ke_c * HRT_BLOCK);
+        const bool sc1_in = b != b0;
+        for (uint32_t chunk_c = blockIdx.x; chunk_c < n_chunks_c; chunk_c += G) {
+#include "hrt_fused_body.inc"
         }
-        __syncthreads();
-        // (L.wcnt[16 ..]: K x 4 counts, sub-chunk-major = entry order)
-#pragma unroll
-        for (int q = 0; q < 4 * K; ++q) c_total += L.wcnt[16 + q];
-        if (tid == 0) lb_store(W.chunk + chunk, kLbDone | c_total);
+        if (b == P.num_bounces) return;
+        if (!chain_barrier(lb_words(P, b - 1u), kChainTag | b, G, err_word, P.host_flag, P.tune.lb_max_polls, &L.wcnt[9])) return;
     }
-    HRT_PHASE(10);
-
-    // ---- (3) scatter records of bounce b-1: shadow ray to every RX, in order (unless hrt_records_kernel's) ----
-    if constexpr (!FIRST) if (!P.records_done) {
-        const uint32_t pb = b - 1;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t i = chunk * MC + (uint32_t)k * HRT_BLOCK + tid;
-            const uint32_t i4 = i * 4u;
-            if (HRT_BALLOT(valid[k]) == 0ull) continue;   // wave-uniform: past the end of the list
-            const Ball ball = (VARIANT >= 2 && VARIANT != 6 && !masked) ? origin_ball(o[k], valid[k])
-                                                                       : Ball{{0.f, 0.f, 0.f}, 0.f, false};
-            F3 n = {0.f, 0.f, 1.f}, mvel = {0.f, 0.f, 0.f};
-            float mat_s = 0.f, mat_alpha = 1.f, th = theta[k];
-            if (valid[k]) {
-                uint32_t ht = htri[k];
-                if (ht >= T) {   // cannot happen; never fault
-                    atomicOr(&counts[P.num_bounces + 1], 4u);
-                    ht = 0u;
-                }
-                const float4 q2 = tri[HRT_ROW * ht + 2];
-                n = {q2.y, q2.z, q2.w};
-                const uint32_t mesh = __float_as_uint(tri[HRT_ROW * ht + 4].w);
-                const float4 mm = gather4(mesh_r, HRT_MESH_FLOATS * 4u, mesh, 0u);
-                mvel = {mm.x, mm.y, mm.z};
-                const float4 m3 = L.mat[4u * __float_as_uint(mm.w) + 3u];
-                mat_s = m3.x;
-                mat_alpha = m3.y;
-            }
-            for (uint32_t rx = 0; rx < P.num_rx; ++rx) {
-                const float4 rp = L.rx[rx];
-                const F3 apex = {rp.x, rp.y, rp.z};
-                float d2rx;
-                F3 w = shadow_dir(o[k], apex, d2rx);
-                if (!valid[k]) w = {0.f, 0.f, 1.f};
-                const Hit sh = masked ? closest_hit_masked(tri, P.acc.orig, P.rxt, rx, T, o[k], w, valid[k], lane, 2)
-                                      : closest_hit<VARIANT>(tri, tg, leaf, P.acc, P.rxt, rx, P.acc.orig, T, o[k], w, valid[k],
-                                                             lane, ball, true, apex, L.mask, L.wleaf, 2);
-                bool unblocked = false;
-                if (valid[k]) {
-                    const Rsrc rec = rec_blk(P, pb, rx);
-                    if (sh.tri != HRT_NO_HIT) {
-                        const float4 s2 = tri[HRT_ROW * sh.tri + 2];
-                        th = incidence_angle({s2.y, s2.z, s2.w}, w);
-                    }
-                    if (sh.tri != HRT_NO_HIT && sh.t <= 1.f) {
-                        stf(rec, R_A0 * cap4, i4, 0.f);
-                        stf(rec, R_A1 * cap4, i4, 0.f);
-                        stf(rec, R_A2 * cap4, i4, 0.f);
-                        stf(rec, R_A3 * cap4, i4, 0.f);
-                        stf(rec, R_TAU * cap4, i4, 0.f);
-                    } else {
-                        unblocked = true;
-                        const float th_s = acos_f_ool(dot3(w, n));
-                        const float4 S = scatter_pattern(mat_s, mat_alpha, th_s, th);
-                        float o0 = a0[k] * S.x - a1[k] * S.y;
-                        float o1 = a0[k] * S.y + a1[k] * S.x;
-                        float o2 = a2[k] * S.z - a3[k] * S.w;
-                        float o3 = a2[k] * S.w + a3[k] * S.z;
-                        float f2 = P.fsl_mult * d2rx;
-                        f2 *= f2;
-                        if (f2 > 1.f) { o0 /= f2; o1 /= f2; o2 /= f2; o3 /= f2; }
-                        stf(rec, R_A0 * cap4, i4, o0);
-                        stf(rec, R_A1 * cap4, i4, o1);
-                        stf(rec, R_A2 * cap4, i4, o2);
-                        stf(rec, R_A3 * cap4, i4, o3);
-                        stf(rec, R_TAU * cap4, i4, tau[k] + d2rx / kC);
-                        stf(rec, R_DX * cap4, i4, -w.x);
-                        stf(rec, R_DY * cap4, i4, -w.y);
-                        stf(rec, R_DZ * cap4, i4, -w.z);
-                        stf(rec, R_DFS * cap4, i4, dot3(sub3(w, d[k]), mvel) * P.dop_mult);
-                    }
-                }
-                const unsigned long long um = HRT_BALLOT(unblocked);
-                if (lane == 0 && valid[k]) mask_words(P, pb, rx)[i >> 6] = um;
-            }
-        }
-    }
-
-    HRT_PHASE(11);
-    // ---- (4) survivors of all earlier macro-chunks, (5) the bounce itself (:616-659) and the stores ----
-    if (do_trace) {
-        // Later launches: what the shading reads from memory -- the hit triangle's normal and material --
-        // is requested HERE, in front of the wait, so that the shading loop behind it has no load in
-        // front of its stores (C4 launch 1: 0.345 -> 0.329 ms).  Launch 0 keeps its registers instead
-        // (7 waves per SIMD): it reads the launch ray AGAIN inside the loop (id and direction were not
-        // kept through the traces; the lines were touched a few us ago: L2 / MALL hits) -- hoisting
-        // those K * 12 registers in front of the wait spills and costs more than it hides (0.309 -> 0.355).
-        F3 nk[K];
-        uint32_t matk[K];
-        if constexpr (!FIRST) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                nk[k] = {0.f, 0.f, 1.f};
-                matk[k] = 0u;
-                if (valid[k] && h[k].tri != HRT_NO_HIT) bounce_fetch(tri, mesh_r, h[k].tri, nk[k], matk[k]);
-            }
-        }
-        // A chunk without survivors stores nothing: it needs its prefix only if somebody else needs
-        // something FROM it -- it closes a group / supergroup (their totals), or it is the last chunk (the
-        // list's length).  Half of C4's launch-0 chunks (the upper hemisphere) and nearly all of its
-        // launch-1 chunks leave here without waiting for the chunks in front of them (C4 0.725 -> 0.68 ms).
-        // (Requesting the words before the first packet is shaded and looking at them after it -- the
-        // packet's result waiting in registers -- was measured too: spills at 7 waves, 0.265 -> 0.29 ms.)
-        const bool need_prefix = c_total != 0u || (chunk & 63u) == 63u || chunk + 1u == n_chunks;
-        if (need_prefix) {   // (uniform over the workgroup)
-            if (tid < 64u) {   // wave 0
-                const uint32_t excl = lb_exclusive(W, chunk, c_total, lane, &counts[P.num_bounces + 1], P.host_flag, P.tune.lb_max_polls);
-                if (lane == 0) {
-                    L.wcnt[8] = excl;
-                    if (excl != kLbAbort && chunk + 1u == n_chunks) counts[b + 1] = excl + c_total;   // the next live list's length
-                }
-            }
-            __syncthreads();
-            if (L.wcnt[8] == kLbAbort) return;   // (uniform) the launch is void: see lb_exclusive
-        }
-        HRT_PHASE(12);
-        uint32_t pos = L.wcnt[8];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            // survivors of this wave's k-th packet start behind those of (k, earlier waves)
-            uint32_t before = 0u, sub = 0u;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t cw = L.wcnt[16 + k * 4 + w];
-                before += ((uint32_t)w < wave) ? cw : 0u;
-                sub += cw;
-            }
-            const bool hit = valid[k] && h[k].tri != HRT_NO_HIT;
-            if (hit) {
-                float nth = 0.f;
-                if constexpr (FIRST) {   // src/compute_paths.c:460-466 state init, :494-500 the launch Doppler term
-                    // (issuing these loads one packet ahead of the stores -- loads and stores share vmcnt --
-                    // was measured too: 12 more registers, spills at 7 waves, 0.309 -> 0.34 ms on C4)
-                    launch_entry(k);
-                    const uint32_t tx = htri[k];
-                    o[k] = tx_origin(k);
-                    const F3 tv = {P.tx_vel[3 * tx], P.tx_vel[3 * tx + 1], P.tx_vel[3 * tx + 2]};
-                    fs0[k] = dot3(tv, d[k]) * P.dop_mult;
-                    bounce_fetch(tri, mesh_r, h[k].tri, nk[k], matk[k]);
-                }
-                bounce_apply<(FIRST && HRT_FUSED_INLINE0)>(L.mat, P.fsl_mult, nk[k], matk[k], h[k].t, o[k], d[k], a0[k], a1[k], a2[k], a3[k], tau[k], nth);
-                const uint32_t k4 = (pos + before + lane_prefix(hm[k])) * 4u;
-                store_survivor(hit_out(P, b), cap4, k4, ray[k], h[k].tri, nth, fs0[k], o[k], d[k], a0[k], a1[k], a2[k],
-                               a3[k], tau[k]);
-            }
-            pos += sub;
-        }
-        HRT_PHASE(13);
-    }
-#undef HRT_PHASE
 }
 
 // LoS pass (src/compute_paths.c:515-577): one WAVE per (rx, tx) pair, the lanes share the
@@ -4137,6 +3947,38 @@ static void launch_fused_t(const hrt_kparams *P, uint32_t bounce, size_t lds, hi
     }
 }
 
+// launches b0 .. num_bounces as one persistent kernel (hrt_chain_kernel); -1: not on this problem (the caller
+// launches them one by one)
+template <int V>
+static void launch_chain_t(const hrt_kparams *P, uint32_t b0, size_t lds, hipStream_t st, hipError_t *err)
+{
+    constexpr int K = HRT_FUSED_KB;
+    const void *fn = reinterpret_cast<const void *>(&hrt_chain_kernel<true, V, K>);
+    // the grid = what is resident at once (asked once per kernel and LDS size; the device is the current one)
+    static size_t known_lds = ~(size_t)0;
+    static int known_dev = -1;
+    static uint32_t known_grid = 0;
+    int dev = 0;
+    if ((*err = hipGetDevice(&dev)) != hipSuccess) return;
+    if (known_lds != lds || known_dev != dev) {
+        if (lds > 64u * 1024u &&
+            (*err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return;
+        int per_cu = 0, cus = 0;
+        if ((*err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)HRT_BLOCK, lds)) != hipSuccess) return;
+        if ((*err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return;
+        if (per_cu < 1 || cus < 1) { *err = hipErrorNotSupported; return; }
+        known_grid = (uint32_t)per_cu * (uint32_t)cus;
+        known_lds = lds;
+        known_dev = dev;
+    }
+    uint32_t grid = known_grid;
+    // (never more workgroups than macro-chunks of one packet per wave the list can have)
+    const uint64_t most = (P->cap + HRT_BLOCK - 1) / HRT_BLOCK;
+    if (grid > most) grid = (uint32_t)(most ? most : 1u);
+    if (grid > kChainMaxGrid) grid = kChainMaxGrid;   // (64 groups of 64: chain_barrier)
+    hipLaunchKernelGGL((hrt_chain_kernel<true, V, K>), dim3(grid), dim3(HRT_BLOCK), lds, st, *P, b0);
+}
+
 // ===================================================================================
 // Export of a rank's compact result as ONE contiguous run of 32-bit words (csrc/host/gather.c; layout in
 // include/hrt_device.h): the only exchange step of the sharded path is the gather of these runs to one rank.
@@ -4486,6 +4328,40 @@ int hrt_hip_launch_fused(const hrt_kparams *P_in, uint32_t bounce, void *stream)
         else launch_fused_t<false, 5>(P, bounce, lds, st, &err);
     }
     if (err == hipErrorNotSupported) return -1;   // not a HIP failure: this launch runs as two kernels
+    if (err != hipSuccess) return (int)err;
+    return (int)hipGetLastError();
+}
+
+int hrt_hip_launch_chain(const hrt_kparams *P_in, uint32_t b0, void *stream)
+{
+    if (b0 == 0 || b0 > P_in->num_bounces) return -1;
+    hrt_kparams Pc = *P_in;
+    Pc.records_done = 0u;
+    Pc.los_blocks = 0;
+    const hrt_kparams *P = &Pc;
+    if (records_in_own_kernel(P_in, b0)) return -1;
+    if (P->cap / HRT_BLOCK + 1u > P->lb_chunks) return (int)hipErrorInvalidValue;
+    const int variant = P->tune.variant;
+    const uint64_t T = P->num_tri;
+    const uint64_t tri_bytes = T * HRT_TRI_FLOATS * 4u + ((T + 1u) / 2u) * 16u +
+                               (uint64_t)P->acc.num_leaf * HRT_NODE_FLOATS * 4u;
+    const bool in_lds = T * HRT_TRI_FLOATS * 4u <= P->tune.lds_tri_bytes_max && tri_bytes <= 144u * 1024u;
+    const bool one_block = P->num_tri <= kMaskRounds * 64u;
+    if (!in_lds || !one_block || walks_fine(P)) return -1;
+    const size_t lds = (size_t)tri_bytes + (size_t)P->num_rx * 16u +
+                       (HRT_BLOCK / 64u) * (kMaskRounds * 8u + wave_scratch4(false) * 16u) + 64u * 4u +
+                       (size_t)(HRT_NUM_MATERIALS * HRT_MAT_FLOATS * 4u) + kLdsTx * 16u;
+    const bool trees = P->acc.big && (variant >= 4) && variant != 9;
+    const bool flat = variant == 2 || variant == 3 || (variant == 7 && !trees && one_block);
+    const bool staged = variant == 1 || (variant == 7 && T <= P->tune.fuse_staged_max_tri);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    if (variant == 0) launch_chain_t<0>(P, b0, lds, st, &err);
+    else if (staged) launch_chain_t<1>(P, b0, lds, st, &err);
+    else if (flat) launch_chain_t<2>(P, b0, lds, st, &err);
+    else if (trees) return -1;
+    else launch_chain_t<4>(P, b0, lds, st, &err);
+    if (err == hipErrorNotSupported) return -1;
     if (err != hipSuccess) return (int)err;
     return (int)hipGetLastError();
 }

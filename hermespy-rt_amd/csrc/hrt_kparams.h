@@ -12,6 +12,9 @@ extern "C" {
 #define HRT_NO_HIT 0xFFFFFFFFu
 #define HRT_ERR_FUSE_TIMEOUT 0x100u   /* error word of a trace (counts[nb + 1]): a fused launch timed out waiting for its
                                        * prefix (GPU shared with other fused kernels); the step is void, redo it unfused */
+#define HRT_ERR_CHAIN_TIMEOUT 0x200u  /* ... the kernel that runs launches 1 .. nb as one (hrt_chain_kernel) found its grid not
+                                       * resident, or timed out in a grid barrier; the step is void, redo it launch by launch */
+#define HRT_ERR_VOID (HRT_ERR_FUSE_TIMEOUT | HRT_ERR_CHAIN_TIMEOUT)
 #define HRT_NUM_MATERIALS 17
 #define HRT_TRI_FLOATS 20  /* v1(3) e1(3) e2(3) n(3) E_d c_uv c_w (culling tolerances) |e1| |e2| |e2-e1| |e1xe2| mesh_id(u32) */
 #define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */
@@ -200,8 +203,9 @@ typedef struct {
     uint32_t phase_bounce;   /* -DHRT_PHASE_STATS builds: the launch whose workgroups record their time stamps */
     uint32_t fuse;        /* HRT_FUSE_*: which launches run as ONE kernel (trace + shade + compaction) */
     uint32_t cnt_stride;  /* HRT_CNT_STRIDE(num_bounces): bytes between the parts of the counter block */
-    uint32_t *host_flag;  /* a word in page-locked host memory (device address): set to 1 when a fused launch gives up
-                           * waiting (HRT_ERR_FUSE_TIMEOUT) -- the host sees it without synchronising; or NULL */
+    uint32_t *host_flag;  /* two words in page-locked host memory (device address): [0] set to 1 when a fused launch gives
+                           * up waiting (HRT_ERR_FUSE_TIMEOUT), [1] when the chain kernel does (HRT_ERR_CHAIN_TIMEOUT) --
+                           * the host sees them without synchronising; or NULL */
     uint32_t records_done; /* set by the shade shim: hrt_records_kernel wrote this launch's records (patch tables) */
     /* queue of the packets that are too wide to cull (big tables, hrt_wide_kernel): wide_cap entries of
      * 8 bytes at off_wide_q, 64 keys of 8 bytes per entry at off_wide_key; the per-launch entry counts are
@@ -249,6 +253,7 @@ int hrt_hip_launch_shade(const hrt_kparams *P, uint32_t bounce, void *stream);
 
 int hrt_hip_launch_fused(const hrt_kparams *P, uint32_t bounce, void *stream);   /* -1: not fusable, nothing launched */
 int hrt_hip_launch_records(const hrt_kparams *P, uint32_t bounce, void *stream); /* -1: not applicable, nothing launched */
+int hrt_hip_launch_chain(const hrt_kparams *P, uint32_t b0, void *stream);        /* launches b0 .. nb as one kernel; -1: not applicable */
 int hrt_hip_event_create_sync(void **ev);
 int hrt_hip_stream_wait_event(void *stream, void *ev);
 int hrt_hip_launch_dirs(uint64_t num_paths, uint32_t rank, uint32_t count, uint32_t chunk,

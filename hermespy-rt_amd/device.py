@@ -213,10 +213,10 @@ class Tracer:
         c = self._view(int(self.layout.off_counts), self.nb + 2, torch.int32).cpu().numpy()
         c = c.astype(np.int64) & 0xFFFFFFFF
         c[0] = self.ntx * self.num_local
-        if int(c[self.nb + 1]) & 0x100:   # HRT_ERR_FUSE_TIMEOUT (hrt_kparams.h)
-            raise _lib.HrtError("a fused launch timed out waiting for its prefix sums (the GPU is shared with other "
-                                "fused kernels): this step is void -- trace() again; the library has switched to two "
-                                "kernels per launch for the rest of the process")
+        if int(c[self.nb + 1]) & 0x300:   # HRT_ERR_FUSE_TIMEOUT | HRT_ERR_CHAIN_TIMEOUT (hrt_kparams.h)
+            raise _lib.HrtError("a fused launch timed out waiting for the workgroups in front of it (the GPU is shared "
+                                "with other such kernels): this step is void -- trace() again; the library has switched "
+                                "to smaller kernels for the rest of the process")
         if c[self.nb + 1] != 0:   # set by the shade kernel if a trace result was out of range
             raise _lib.HrtError("device reported an internal error flag %d" % int(c[self.nb + 1]))
         return c

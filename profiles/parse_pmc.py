@@ -80,7 +80,7 @@ write = [x * raw["WRITE_SIZE"]["corr"] * 1024 for x in raw["WRITE_SIZE"]["per_la
 path = os.path.join(HERE, "pmc_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[workload] = dict(
-    kernels_sha16=hashlib.sha256(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", "hrt_kernels.hip"), "rb").read()).hexdigest()[:16],
+    kernels_sha16=hashlib.sha256(b"".join(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", f), "rb").read() for f in ("hrt_kernels.hip", "hrt_fused_body.inc"))).hexdigest()[:16],
     n_gpus=1, kernel="per launch: hrt_fused_kernel, or hrt_records_kernel + hrt_image_kernel / hrt_trace_kernel + hrt_shade_kernel", round=tag,
     by_kernel_bytes_per_step={k: dict(fetch=raw["FETCH_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["FETCH_SIZE"]["corr"] * 1024,
                                       write=raw["WRITE_SIZE"]["by_kernel_KiB_per_step"].get(k, 0) * raw["WRITE_SIZE"]["corr"] * 1024)

@@ -49,7 +49,7 @@ for kern in ("fused", "records", "image", "trace", "shade"):
 path = os.path.join(HERE, "pmc_valu.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[workload] = dict(
-    kernels_sha16=hashlib.sha256(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", "hrt_kernels.hip"), "rb").read()).hexdigest()[:16],
+    kernels_sha16=hashlib.sha256(b"".join(open(os.path.join(REPO, "hermespy-rt_amd", "csrc", f), "rb").read() for f in ("hrt_kernels.hip", "hrt_fused_body.inc"))).hexdigest()[:16],
     round=tag, kernels=out,
     source="rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES (profiles/%s_pmc_valu_%s.csv); "
            "cycles_per_valu_inst = 1024 SIMDs * busy cycles per XCD / insts; the SIMD-32 peak is "
