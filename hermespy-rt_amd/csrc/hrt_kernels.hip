@@ -3955,9 +3955,10 @@ static void launch_chain_t(const hrt_kparams *P, uint32_t b0, size_t lds, hipStr
     constexpr int K = HRT_FUSED_KB;
     const void *fn = reinterpret_cast<const void *>(&hrt_chain_kernel<true, V, K>);
     // the grid = what is resident at once (asked once per kernel and LDS size; the device is the current one)
-    static size_t known_lds = ~(size_t)0;
-    static int known_dev = -1;
-    static uint32_t known_grid = 0;
+    // (per host thread: the drop-in call drives several devices from several threads)
+    static thread_local size_t known_lds = ~(size_t)0;
+    static thread_local int known_dev = -1;
+    static thread_local uint32_t known_grid = 0;
     int dev = 0;
     if ((*err = hipGetDevice(&dev)) != hipSuccess) return;
     if (known_lds != lds || known_dev != dev) {

@@ -39,9 +39,9 @@ from tests import scenes_gen as G              # noqa: E402
 from tests.parity import compare_dense         # noqa: E402
 
 
-def soup_case(seed, tmp):
+def soup_case(seed, tmp, max_tri=900):
     rng = np.random.default_rng(50000 + seed)
-    T = int(rng.integers(1, 900))
+    T = int(rng.integers(1, max_tri))
     scale = [1.0, 30.0, 0.05, 300.0][seed % 4]
     c0 = rng.uniform(-1, 1, (T, 3)) * scale
     ext = scale * rng.choice([0.02, 0.2, 1.0])
@@ -110,6 +110,20 @@ def bigsoup_case(seed, tmp):
     return c
 
 
+def deepsoup_case(seed, tmp):
+    """a soup traced deep: 4-8 bounces with tens of thousands of rays -- the tail of the launches as one
+    persistent kernel (hrt_chain_kernel) on random geometry, lists of many chunks at its first bounces"""
+    c = soup_case(seed, tmp, max_tri=65)   # (whole bounces are fused up to 64 triangles)
+    rng = np.random.default_rng(57000 + seed)
+    c["num_paths"] = int(rng.integers(40000, 160000))
+    c["num_bounces"] = int(rng.integers(4, 9))
+    if seed % 2 == 0:      # endpoints inside the soup: rays keep hitting
+        scale = [1.0, 30.0, 0.05, 300.0][seed % 4]
+        c["rx_pos"] = (rng.uniform(-0.4, 0.4, (len(c["rx_pos"]), 3)) * scale).tolist()
+        c["tx_pos"] = (rng.uniform(-0.4, 0.4, (len(c["tx_pos"]), 3)) * scale).tolist()
+    return c
+
+
 def check(L, c):
     got = abi.run_compute_paths(L, *K.args(c))
     ref = oracle.compute_paths(*K.args(c))
@@ -127,6 +141,8 @@ def main():
     for seed in range(lo, hi):
         if mode == "bigsoups":
             c = bigsoup_case(seed, tmp)
+        elif mode == "deepsoups":
+            c = deepsoup_case(seed, tmp)
         else:
             c = _case(seed) if mode == "configs" else (big_case(seed) if mode == "big" else
                                                       (inplane_case(seed) if mode == "inplane" else soup_case(seed, tmp)))
