@@ -20,6 +20,10 @@ HRT_OVERLAP=0 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format
 d=gpurun_out/prof_${tag}_${w}_overlap
 rm -rf $d
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- $B --steps 20 --warmup 5 > $d.json 2> $d.err || (tail -20 $d.err; exit 1)
+# (PMC passes: a kernel per launch -- HRT_TUNE=no_chain=1 -- so that every step of the pass, timed or with events, has
+# the same kernel sequence and the per-launch sums mean what the bench line's per-launch times mean; the kernel-stats
+# runs above keep the default, i.e. show hrt_chain_kernel where it is used: tables of <= 64 triangles, >= 4 bounces)
+export HRT_TUNE=no_chain=1
 for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/pmc_${tag}_${w}_$c
   rm -rf $d

@@ -28,6 +28,8 @@ def newest(pattern):
 def kind(name):
     if "hrt_fused_kernel" in name:
         return "fused"
+    if "hrt_chain_kernel" in name:   # (not in the PMC passes: collect_all.sh runs them with no_chain=1)
+        return "chain"
     if "hrt_records_kernel" in name:
         return "records"
     if "hrt_image_kernel" in name:
@@ -66,7 +68,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         k = kind(r["Kernel_Name"])
         # a launch begins with its fused kernel, with its records kernel (patch tables: shadow traces + records), or
         # with the kernel of its primary rays when no records kernel went before
-        if k in ("fused", "records") or (k in ("trace", "image") and prev != "records"):
+        if k in ("fused", "chain", "records") or (k in ("trace", "image") and prev != "records"):
             per.append(0.0)
         prev = k
         per[-1] += float(r["Counter_Value"])
