@@ -143,6 +143,17 @@ typedef struct {
     uint64_t unblocked[HRT_MAX_SCATTER_THREADS];
 } scatter_ctx;
 
+/* The slim path forms tau and directions_rx HERE with the reference's float sequence: the bits only match the
+ * device's if nothing in this file is contracted into an FMA.  The Makefile says -ffp-contract=off; so does the source */
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT OFF
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+#if defined(__FAST_MATH__)
+#error "compute_paths.c must not be built with -ffast-math: the slim records are formed on the host bit-exactly"
+#endif
+
 /* records of (bounce b, rx) -> dense slots ((rx*ntx+tx)*nb+b)*np+p   (src/compute_paths.c:674).
  * The index arithmetic is the hot part of the host side (27 M records on C3): the 64-bit
  * divisions of the general shard mapping cost more than the nine stores, so the two common cases
@@ -305,7 +316,7 @@ static int parse_devices(int *dev)
  * needs.  C4 holds 14 GB -- its warm call is 0.04 s with them kept, 0.24 s without: such a caller raises it) are
  * not kept. */
 typedef struct {
-    int valid, device, with_rays;
+    int valid, device, with_rays, slim;
     uint64_t cap, ws_bytes, dirs_rows;
     work_t w;
 } pool_slot;
@@ -360,10 +371,11 @@ int hrt_worker_alloc(dev_ctx *c)
     const uint64_t n_loc_max = hrt_shard_num_local(&(hrt_shard){np, 0, c->G, 0, (uint32_t)nb});
     const uint64_t cap = L.cap;
     const int with_rays = c->scat_rays != NULL;
+    const int slim = !env_int("HRT_FULL_RECORDS", 0);   /* (the per-hit staging arrays hs / hs2 exist only then) */
     if (c->use_pool) {
         pool_slot *ps = &g_pool[c->index];
         if (ps->valid && ps->device == c->device && ps->cap >= cap && ps->ws_bytes >= L.total_bytes &&
-            ps->dirs_rows >= n_loc_max + 64 && ps->with_rays >= with_rays) {
+            ps->dirs_rows >= n_loc_max + 64 && ps->with_rays >= with_rays && ps->slim >= slim) {
             *w = ps->w;
             c->cap_alloc = ps->cap; c->ws_alloc = ps->ws_bytes; c->dirs_rows_alloc = ps->dirs_rows;
             memset(ps, 0, sizeof *ps);
@@ -399,7 +411,7 @@ int hrt_worker_alloc(dev_ctx *c)
     ok &= hrt_hip_host_malloc((void **)&w->fs0, cap * 4) == 0;
     ok &= hrt_hip_host_malloc((void **)&w->mask, cap / 64 * 8 + 8) == 0;
     for (int k = 0; k < 6 && with_rays; ++k) ok &= hrt_hip_host_malloc((void **)&w->st[k], cap * 4) == 0;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 4 && slim; ++k) {
         ok &= hrt_hip_host_malloc((void **)&w->hs[k], cap * 4) == 0;
         ok &= hrt_hip_host_malloc((void **)&w->hs2[k], cap * 4) == 0;
     }
@@ -426,7 +438,7 @@ void hrt_worker_release(dev_ctx *c)
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
         if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);
         pool_slot *ps = &g_pool[c->index];
-        ps->valid = 1; ps->device = c->device; ps->with_rays = w->st[0] != NULL;
+        ps->valid = 1; ps->device = c->device; ps->with_rays = w->st[0] != NULL; ps->slim = w->hs[0] != NULL;
         ps->cap = c->cap_alloc; ps->ws_bytes = c->ws_alloc; ps->dirs_rows = c->dirs_rows_alloc;
         ps->w = *w;
         memset(w, 0, sizeof *w);

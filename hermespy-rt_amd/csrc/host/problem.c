@@ -1294,7 +1294,10 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
     STEP(hrt_hip_memset_async((uint8_t *)d_ws + L.off_counts, 0, L.off_los - L.off_counts, stream));
     /* the LoS pass: its own (tiny) kernel, or -- when launch 0 is one fused kernel -- a few extra
      * workgroups of that kernel (a launch less: it matters on launch sets of a few 10^4 rays) */
-    K.los_blocks = (K.fuse & HRT_FUSE_LAUNCH0) ? 1u : 0u;
+    /* (big tables with few pairs: the sliced LoS kernel, hrt_los_big_kernel, not one wave per pair as the tail of
+     * launch 0 -- 0.8 ms per 100 k triangles) */
+    K.los_blocks = ((K.fuse & HRT_FUSE_LAUNCH0) &&
+                    !(p->num_tri >= p->tune.k.los_big_min_tri && (uint64_t)p->num_rx * p->num_tx <= 32u)) ? 1u : 0u;
     if (ev) STEP(hrt_hip_event_record(ev[0], stream));
     if (!K.los_blocks) STEP(hrt_hip_launch_los(&K, stream));
     if (ev) STEP(hrt_hip_event_record(ev[1], stream));
@@ -1350,6 +1353,11 @@ static int trace_impl(const hrt_problem *p, const hrt_shard *s, const float *d_d
         if (fused_rc < 0 && b == 0 && K.los_blocks) {   /* launch 0 is not fused after all: the LoS pass as its own kernel */
             K.los_blocks = 0u;
             STEP(hrt_hip_launch_los(&K, stream));
+            if (ev) {   /* (the timer: LoS ends here, launch 0 begins here) */
+                STEP(hrt_hip_event_record(ev[1], stream));
+                STEP(hrt_hip_event_record(ev[2], stream));
+                STEP(hrt_hip_event_record(ev[4], stream));
+            }
         }
         if (fused_rc >= 0) {
             STEP(fused_rc);
