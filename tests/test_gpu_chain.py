@@ -88,3 +88,27 @@ tr.close()
             else:
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
         assert nb == 5
+
+
+CODE_BIG = r"""
+import sys
+sys.path.insert(0, %(repo)r)
+from hermespy_rt_amd import abi, lib
+from oracle import oracle
+from tests import configs as K
+from tests.parity import compare_dense
+L = lib.load()
+c = dict(K.small(K.C3_DOPPLER, 120000), num_bounces=5)
+st = compare_dense(abi.run_compute_paths(L, *K.args(c)), oracle.compute_paths(*K.args(c)))
+assert all(v == 0 for v in st.values()), st
+print("CHAIN_OK")
+"""
+
+
+@pytest.mark.parametrize("variant", [2, 4])
+def test_chain_kernel_on_a_table_of_one_culling_block(variant):
+    """HRT_FUSE=2 fuses whole bounces on any table of one culling block (<= 1 024 triangles): the chain kernel with
+    the packet-culling walks (234 triangles in LDS), flat and behind the leaf spheres"""
+    env = tuned(HRT_FUSE=2, no_patch=1, chain_from=1, variant=variant)
+    p = subprocess.run([sys.executable, "-c", CODE_BIG % dict(repo=REPO)], env=env, capture_output=True, text=True)
+    assert p.returncode == 0 and "CHAIN_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
