@@ -9,10 +9,16 @@
 //   hrt_trace_kernel   the moeller_trumbore calls of :615 and :682 (all traces of a launch)
 //   hrt_shade_kernel   src/compute_paths.c:460-466 (state init), :616-664 (Fresnel, FSL,
 //                      reflect), :671-723 (scatter records)
+//   hrt_fused_kernel   both of the above for one launch in ONE kernel (launch 0 always; every launch on
+//                      tables of <= 64 triangles; body: hrt_fused_body.inc), hrt_chain_kernel: the tail of
+//                      such launches as one persistent kernel with grid barriers
+//   hrt_records_kernel :671-723 on tables of 65-256 triangles (patch tables): the shadow traces and the
+//                      scatter records of a launch; hrt_image_kernel: the primary rays of launch 1 there
 //   hrt_los_kernel     src/compute_paths.c:515-577
 //
 // Design (MI355X-first, not the reference's loop nest):
-//   * Per launch b two kernels over the COMPACT live list of launch b-1 (the rays that hit at
+//   * The general form (any table; the small tables use the kernels above):
+//     per launch b two kernels over the COMPACT live list of launch b-1 (the rays that hit at
 //     bounce b-1, with their post-reflection state; at b = 0 the launch set in a coherent order).
 //     hrt_trace_kernel does all intersection work -- per entry the num_rx shadow rays of bounce
 //     b-1 and the ray of bounce b -- and hrt_shade_kernel everything per ray that is not
