@@ -340,6 +340,19 @@ static void pool_release_all(void)
         if (rc) goto done;                                                               \
     } while (0)
 
+/* device + page-locked bytes a worker holds for batches of `cap` entries (workspace, launch tables, staging) */
+uint64_t hrt_worker_held_bytes(uint64_t ws_bytes, uint64_t dirs_rows, uint64_t cap)
+{
+    return ws_bytes + dirs_rows * 16 + cap * 4 * (5 + 2 * HRT_REC_FIELDS + 6 + 8);
+}
+/* may a batch of this size be chosen by default?  (the pool is on and the caller did not set the budget: then what
+ * a worker holds must fit the pool, or every call allocates it again) */
+int hrt_batch_fits_pool(uint64_t ws_bytes, uint64_t dirs_rows, uint64_t cap)
+{
+    if (env_u64("HRT_WORKSPACE_BYTES", 0) || env_int("HRT_NO_CACHE", 0)) return 1;
+    return hrt_worker_held_bytes(ws_bytes, dirs_rows, cap) <= env_u64("HRT_POOL_MAX_BYTES", HRT_POOL_MAX_DEFAULT);
+}
+
 /* one call at a time owns the pool (compute_paths is not re-entrant; a concurrent call just
  * allocates its own buffers) */
 int hrt_pool_begin(void)
@@ -433,8 +446,8 @@ void hrt_worker_release(dev_ctx *c)
     free(w->cur_rays); w->cur_rays = NULL;
     free(w->active); free(w->next_active); w->active = w->next_active = NULL;
     free(w->dirs_batch); w->dirs_batch = NULL;
-    const uint64_t held = c->ws_alloc + c->dirs_rows_alloc * 16 + c->cap_alloc * 4 * (5 + 2 * HRT_REC_FIELDS + 6 + 8);
-    if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", 5ull << 30)) {
+    const uint64_t held = hrt_worker_held_bytes(c->ws_alloc, c->dirs_rows_alloc, c->cap_alloc);
+    if (c->use_pool && c->rc == HRT_OK && w->d_ws && held <= env_u64("HRT_POOL_MAX_BYTES", HRT_POOL_MAX_DEFAULT)) {
         if (w->copy_stream) hrt_hip_stream_sync(w->copy_stream);
         if (w->copy_stream2) hrt_hip_stream_sync(w->copy_stream2);
         pool_slot *ps = &g_pool[c->index];
@@ -867,11 +880,17 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
             for (int d = 0; d < D; ++d) same += ctx[d].device == ctx[0].device;
             budget /= (uint64_t)(same > 0 ? same : 1);
         }
+        /* ... and, unless the caller set the budget, so that what a worker holds fits the buffer pool (hrt_worker_release):
+         * buffers above HRT_POOL_MAX_BYTES are freed after the call and allocated again by the next one -- C4's 14 GB in
+         * one batch: a warm call of 0.31 s, 0.17 of them hipMalloc / hipHostMalloc / hipFree; in four batches 0.04 s
+         * (the batches' copies and host scatter overlap the next batch's kernels anyway) */
         hrt_layout L;
         for (;;) {
             hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
             rc = hrt_layout_query(prob, &s, &L);
-            if (rc == HRT_OK && G >= (uint32_t)D && L.total_bytes + hrt_shard_num_local(&s) * 12 <= budget) break;
+            const uint64_t n_loc = hrt_shard_num_local(&s);
+            if (rc == HRT_OK && G >= (uint32_t)D && L.total_bytes + n_loc * 12 <= budget &&
+                hrt_batch_fits_pool(L.total_bytes, n_loc + 64, L.cap)) break;
             if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
             if ((uint64_t)G * 4096 >= np) {   /* one granule per batch and still too big */
                 if (rc == HRT_OK) break;      /* try anyway; hipMalloc decides */

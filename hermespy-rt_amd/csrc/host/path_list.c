@@ -169,7 +169,8 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     for (;;) {
         hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
         rc = hrt_layout_query(prob, &s, &L);
-        if (rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 16 <= budget) break;
+        if (rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 16 <= budget &&
+            hrt_batch_fits_pool(L.total_bytes, hrt_shard_num_local(&s) + 64, L.cap)) break;   /* (compute_paths.c) */
         if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
         if ((uint64_t)G * 4096 >= np) {
             if (rc == HRT_OK) break;
