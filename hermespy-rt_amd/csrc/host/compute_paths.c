@@ -885,12 +885,17 @@ static int compute_paths_impl(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_p
          * one batch: a warm call of 0.31 s, 0.17 of them hipMalloc / hipHostMalloc / hipFree; in four batches 0.04 s
          * (the batches' copies and host scatter overlap the next batch's kernels anyway) */
         hrt_layout L;
+        uint32_t G_budget = 0;   /* the first G that fits the memory budget */
         for (;;) {
             hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
             rc = hrt_layout_query(prob, &s, &L);
             const uint64_t n_loc = hrt_shard_num_local(&s);
-            if (rc == HRT_OK && G >= (uint32_t)D && L.total_bytes + n_loc * 12 <= budget &&
-                hrt_batch_fits_pool(L.total_bytes, n_loc + 64, L.cap)) break;
+            const int fits = rc == HRT_OK && G >= (uint32_t)D && L.total_bytes + n_loc * 12 <= budget;
+            if (fits && !G_budget) G_budget = G;
+            /* (the pool rule only where it pays: a call of one or two budget-sized batches per device.  A call of
+             * many batches amortises its allocations -- C5: 0.2 of 3.7 s -- and smaller batches cost it more than
+             * that: 64 instead of 16 took 7.7 s) */
+            if (fits && (G_budget > 2u * (uint32_t)D || hrt_batch_fits_pool(L.total_bytes, n_loc + 64, L.cap))) break;
             if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
             if ((uint64_t)G * 4096 >= np) {   /* one granule per batch and still too big */
                 if (rc == HRT_OK) break;      /* try anyway; hipMalloc decides */

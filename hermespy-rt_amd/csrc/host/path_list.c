@@ -164,13 +164,15 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         budget = free_b / 2;
         if (budget > (16ull << 30)) budget = 16ull << 30;
     }
-    uint32_t G = 1;
+    uint32_t G = 1, G_budget = 0;
     hrt_layout L;
     for (;;) {
         hrt_shard s = {np, 0, G, 0, (uint32_t)nb};
         rc = hrt_layout_query(prob, &s, &L);
-        if (rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 16 <= budget &&
-            hrt_batch_fits_pool(L.total_bytes, hrt_shard_num_local(&s) + 64, L.cap)) break;   /* (compute_paths.c) */
+        const int fits = rc == HRT_OK && L.total_bytes + hrt_shard_num_local(&s) * 16 <= budget;
+        if (fits && !G_budget) G_budget = G;
+        /* (the pool rule for calls of one or two budget-sized batches: compute_paths.c) */
+        if (fits && (G_budget > 2u || hrt_batch_fits_pool(L.total_bytes, hrt_shard_num_local(&s) + 64, L.cap))) break;
         if (rc != HRT_OK && rc != HRT_E_CAPACITY) goto done;
         if ((uint64_t)G * 4096 >= np) {
             if (rc == HRT_OK) break;
