@@ -601,16 +601,16 @@ static int run_batch(dev_ctx *c, uint32_t g)
             }
         }
     }
-    const int can_pre = (ntx == 1) && !scat_rays && !prob->tune.no_bounce_prefetch;
+    const int can_pre = !scat_rays && !prob->tune.no_bounce_prefetch;
     /* slim records (default; HRT_FULL_RECORDS=1 copies all nine fields): see scatter_ctx */
     const int slim = !env_int("HRT_FULL_RECORDS", 0);
     static const int hs_field[4] = {HRT_HIT_OX, HRT_HIT_OY, HRT_HIT_OZ, HRT_HIT_TAU};
-    int pre = 0, flip = 0;   /* staging set of a block: (slot + flip) & 1 */
+    int pre = 0, pre_block_next = 0, flip = 0;   /* staging set of a block: (slot + flip) & 1 */
     for (size_t b = 0; b < nb; ++b) {
         const uint64_t H = w->h_counts[b + 1];
         const uint64_t hb = L.off_hits + b * L.hit_block_bytes;
-        const int prefetched = pre;
-        pre = 0;
+        const int prefetched = pre, pre_block = pre_block_next;   /* this bounce's hit arrays / first block are on their way */
+        pre = 0; pre_block_next = 0;
         if (H && prefetched) {   /* requested during the previous bounce, into the second pair of arrays */
             uint32_t *t_ = w->ray; w->ray = w->ray2; w->ray2 = t_;
             t_ = w->tri; w->tri = w->tri2; w->tri2 = t_;
@@ -669,67 +669,79 @@ static int run_batch(dev_ctx *c, uint32_t g)
             }
             w->run_start[nruns] = H;
         }
-        /* with one run (one TX, the common case) the copy of block rx+1 overlaps the scatter of
-         * block rx; with several runs the blocks are fetched run by run (the reference's order is
-         * (tx, path, rx)) */
-        for (uint64_t run = 0; run < nruns; ++run) {
-            const uint64_t r0 = w->run_start[run], r1 = w->run_start[run + 1];
-            const size_t txr = w->run_tx[run];
-            {
+        /* The blocks of this bounce in the order they are scattered.  rx 0 goes run by run, each run behind its own
+         * Q10 adds: the reference's order (tx, path, rx) on the only slots where order can be seen -- the adds touch
+         * the dense slots [0, ntx*np), which are record slots of rx 0.  Every record of rx >= 1 lives at
+         * ((rx*ntx+tx)*nb+b)*np+p >= ntx*nb*np, beyond anything an add touches, and a record touches its own slot
+         * only: rx >= 1 is scattered over the WHOLE hit list at once, nrx - 1 blocks instead of nruns * (nrx - 1)
+         * (C5, 8 TX x 8 RX: 15 blocks per bounce instead of 64 -- a block costs ~0.1 ms of copies, syncs and
+         * fork/join whatever its size).  The copy of block k+1 overlaps the scatter of block k; behind the last
+         * block the next bounce's hit arrays are requested (and, with one TX, its first block: the runs of several
+         * TXs are only known once the rays are here). */
+        const uint64_t nblk = nruns ? nruns + (nrx - 1) : 0;
+#define BLK_RX(K) ((K) < nruns ? (size_t)0 : (size_t)((K) - nruns + 1))
+#define BLK_I0(K) ((K) < nruns ? w->run_start[(K)] : (uint64_t)0)
+#define BLK_I1(K) ((K) < nruns ? w->run_start[(K) + 1] : H)
+        for (uint64_t k = 0; k < nblk; ++k) {
+            const size_t rx = BLK_RX(k);
+            const uint64_t r0 = BLK_I0(k), r1 = BLK_I1(k);
+            if (k < nruns) {   /* the adds of this run's TX, in front of its records */
+                const size_t txr = w->run_tx[k];
                 q10_ctx qc = {&s, w->ray, w->tri, prob->h_mesh, prob->h_tri_mesh, scat->freq_shift + txr * np,
                               prob->dop_mult, txr * n_loc, r0};
                 hrt_parallel_ranges(q10_range, &qc, r1 - r0, c->scatter_threads);
             }
-            if (run == 0 && !prefetched) {
-                if (flip & 1) FETCH_RX(b, 0, w->rec2, w->mask2, r0, r1);
-                else FETCH_RX(b, 0, w->rec, w->mask, r0, r1);
+            if (k == 0 && !pre_block) {
+                if (flip & 1) FETCH_RX(b, rx, w->rec2, w->mask2, r0, r1);
+                else FETCH_RX(b, rx, w->rec, w->mask, r0, r1);
             }
-            for (size_t rx = 0; rx < nrx; ++rx) {
-                const size_t slot = (size_t)(run * nrx + rx) + (size_t)flip;
-                float *const *cur_rec = (slot & 1) ? w->rec2 : w->rec;
-                const uint64_t *cur_mask = (slot & 1) ? w->mask2 : w->mask;
-                {
-                    int e = hrt_hip_stream_sync(w->copy_stream);   /* block rx has landed */
-                    if (!e) e = hrt_hip_stream_sync(w->copy_stream2);
-                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
-                }
-                if (rx + 1 < nrx || run + 1 < nruns) {   /* next block: rx+1, or rx 0 of the next run */
-                    const size_t nrx_next = (rx + 1 < nrx) ? rx + 1 : 0;
-                    const uint64_t n0_ = (rx + 1 < nrx) ? r0 : w->run_start[run + 1];
-                    const uint64_t n1_ = (rx + 1 < nrx) ? r1 : w->run_start[run + 2];
-                    if (slot & 1) FETCH_RX(b, nrx_next, w->rec, w->mask, n0_, n1_);
-                    else FETCH_RX(b, nrx_next, w->rec2, w->mask2, n0_, n1_);
-                } else if (can_pre && b + 1 < nb && w->h_counts[b + 2] != 0) {
-                    /* the last block of this bounce: the next bounce's rays, triangles and first block */
-                    const uint64_t Hn = w->h_counts[b + 2], hbn = L.off_hits + (b + 1) * L.hit_block_bytes;
-                    int e = hrt_hip_d2h_async(w->ray2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_RAY * L.cap * 4, Hn * 4, w->copy_stream);
-                    if (!e) e = hrt_hip_d2h_async(w->tri2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_TRI * L.cap * 4, Hn * 4, w->copy_stream2);
-                    for (int k = 0; k < 4 && slim && !e; ++k)
-                        e = hrt_hip_d2h_async(w->hs2[k], (const uint8_t *)w->d_ws + hbn + (uint64_t)hs_field[k] * L.cap * 4, Hn * 4,
-                                              (k & 1) ? w->copy_stream2 : w->copy_stream);
-                    if (e) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e); goto done; }
+            const size_t slot = (size_t)k + (size_t)flip;
+            float *const *cur_rec = (slot & 1) ? w->rec2 : w->rec;
+            const uint64_t *cur_mask = (slot & 1) ? w->mask2 : w->mask;
+            {
+                int e = hrt_hip_stream_sync(w->copy_stream);   /* block k has landed */
+                if (!e) e = hrt_hip_stream_sync(w->copy_stream2);
+                if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
+            }
+            if (k + 1 < nblk) {
+                if (slot & 1) FETCH_RX(b, BLK_RX(k + 1), w->rec, w->mask, BLK_I0(k + 1), BLK_I1(k + 1));
+                else FETCH_RX(b, BLK_RX(k + 1), w->rec2, w->mask2, BLK_I0(k + 1), BLK_I1(k + 1));
+            } else if (can_pre && b + 1 < nb && w->h_counts[b + 2] != 0) {
+                /* the last block of this bounce: the next bounce's rays, triangles and (one TX) first block */
+                const uint64_t Hn = w->h_counts[b + 2], hbn = L.off_hits + (b + 1) * L.hit_block_bytes;
+                int e = hrt_hip_d2h_async(w->ray2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_RAY * L.cap * 4, Hn * 4, w->copy_stream);
+                if (!e) e = hrt_hip_d2h_async(w->tri2, (const uint8_t *)w->d_ws + hbn + (uint64_t)HRT_HIT_TRI * L.cap * 4, Hn * 4, w->copy_stream2);
+                for (int q = 0; q < 4 && slim && !e; ++q)
+                    e = hrt_hip_d2h_async(w->hs2[q], (const uint8_t *)w->d_ws + hbn + (uint64_t)hs_field[q] * L.cap * 4, Hn * 4,
+                                          (q & 1) ? w->copy_stream2 : w->copy_stream);
+                if (e) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e); goto done; }
+                pre = 1;
+                if (ntx == 1) {
                     if (slot & 1) FETCH_RX(b + 1, 0, w->rec, w->mask, 0, Hn);
                     else FETCH_RX(b + 1, 0, w->rec2, w->mask2, 0, Hn);
-                    pre = 1;
+                    pre_block_next = 1;
                     flip = (int)((slot + 1) & 1);   /* slot 0 of the next bounce is the set just requested */
                 }
-                {
-                    scatter_ctx sc;
-                    memset(&sc, 0, sizeof sc);
-                    sc.s = &s; sc.ray = w->ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
-                    sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
-                    sc.amp_stride = c->amp_stride;
-                    sc.i_base = r0;
-                    if (slim) {
-                        for (int k = 0; k < 4; ++k) sc.hs[k] = w->hs[k];
-                        sc.rxp[0] = rx_pos[rx].x; sc.rxp[1] = rx_pos[rx].y; sc.rxp[2] = rx_pos[rx].z;
-                    }
-                    if (!prob->tune.no_scatter)   /* (HRT_TUNE no_scatter: timing experiments, copies only) */
-                        hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
-                    for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st->records_unblocked += sc.unblocked[t];
+            }
+            {
+                scatter_ctx sc;
+                memset(&sc, 0, sizeof sc);
+                sc.s = &s; sc.ray = w->ray; sc.rec = cur_rec; sc.mask = cur_mask; sc.scat = scat;
+                sc.n_loc = n_loc; sc.rx = rx; sc.b = b; sc.ntx = ntx; sc.nb = nb; sc.np = np;
+                sc.amp_stride = c->amp_stride;
+                sc.i_base = r0;
+                if (slim) {
+                    for (int q = 0; q < 4; ++q) sc.hs[q] = w->hs[q];
+                    sc.rxp[0] = rx_pos[rx].x; sc.rxp[1] = rx_pos[rx].y; sc.rxp[2] = rx_pos[rx].z;
                 }
+                if (!prob->tune.no_scatter)   /* (HRT_TUNE no_scatter: timing experiments, copies only) */
+                    hrt_parallel_ranges(scatter_range, &sc, r1 - r0, c->scatter_threads);
+                for (int t = 0; t < HRT_MAX_SCATTER_THREADS; ++t) st->records_unblocked += sc.unblocked[t];
             }
         }
+#undef BLK_RX
+#undef BLK_I0
+#undef BLK_I1
 #undef FETCH_RX
 
         /* ---- RaysInfo snapshots (:732-743), this batch's paths.  The state of a ray after bounce b goes
