@@ -247,6 +247,61 @@ static void copy_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
     memcpy(c->dst + i0, c->src + i0, (i1 - i0) * sizeof(float));
 }
 
+/* RaysInfo, this batch's part, on the helper threads (a snapshot is 24 B per launched ray and bounce: 0.5 GB on
+ * C3 -- one thread took 0.15 s of the 0.19 s call for it):
+ * rays_init_range    the launch block: state of local ray il of every TX = {tx_pos, direction}
+ * rays_update_range  after a bounce: the rays that hit take their new state, and their bit in the bounce's
+ *                    active string (atomic OR: neighbouring entries share bytes)
+ * rays_copy_range    the batch's states -> the dense snapshot, granule by granule (item = tx * n_gran + granule) */
+typedef struct {
+    const hrt_shard *s;
+    Ray *cur;                 /* [ntx][n_loc] */
+    const float *dirs;        /* [n_loc][3] */
+    const Vec3 *tx_pos;
+    const uint32_t *ray;
+    float *const *st;         /* o.xyz, d.xyz of the hits */
+    uint8_t *act;
+    Ray *dst;                 /* snapshot base of this bounce: dst + tx * dst_tx_stride + p */
+    uint64_t dst_tx_stride, n_loc, np, n_gran;
+    size_t ntx;
+    uint32_t ch;
+} rays_ctx;
+static void rays_init_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    (void)tid;
+    const rays_ctx *c = (const rays_ctx *)vctx;
+    for (size_t tx = 0; tx < c->ntx; ++tx)
+        for (uint64_t il = i0; il < i1; ++il) {
+            Ray *r = &c->cur[tx * c->n_loc + il];
+            r->o = c->tx_pos[tx];
+            memcpy(&r->d, c->dirs + 3 * il, sizeof(Vec3));
+        }
+}
+static void rays_update_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    (void)tid;
+    const rays_ctx *c = (const rays_ctx *)vctx;
+    for (uint64_t i = i0; i < i1; ++i) {
+        const uint32_t ql = c->ray[i];           /* tx * n_loc + local path */
+        const uint64_t tx = ql / c->n_loc, il = ql - tx * c->n_loc;
+        const uint64_t q = tx * c->np + hrt_shard_global_path(c->s, il);
+        __atomic_fetch_or(&c->act[q / 8], (uint8_t)(1u << (q % 8)), __ATOMIC_RELAXED);
+        Ray *r = &c->cur[ql];
+        r->o = (Vec3){c->st[0][i], c->st[1][i], c->st[2][i]};
+        r->d = (Vec3){c->st[3][i], c->st[4][i], c->st[5][i]};
+    }
+}
+static void rays_copy_range(void *vctx, uint64_t i0, uint64_t i1, int tid)
+{
+    (void)tid;
+    const rays_ctx *c = (const rays_ctx *)vctx;
+    for (uint64_t it = i0; it < i1; ++it) {
+        const uint64_t tx = it / c->n_gran, il = (it - tx * c->n_gran) * c->ch;
+        const uint64_t len = c->n_loc - il < c->ch ? c->n_loc - il : c->ch;
+        memcpy(c->dst + tx * c->dst_tx_stride + hrt_shard_global_path(c->s, il), c->cur + tx * c->n_loc + il, len * sizeof(Ray));
+    }
+}
+
 /* Q10 adds of one TX run (distinct slots: one per ray), see run_batch */
 typedef struct {
     const hrt_shard *s;
@@ -589,19 +644,15 @@ static int run_batch(dev_ctx *c, uint32_t g)
         if (!w->cur_rays) w->cur_rays = (Ray *)malloc(ntx * hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * sizeof(Ray));
         if (!w->cur_rays) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
         const uint32_t ch = s.chunk ? s.chunk : 4096u;
-        for (size_t tx = 0; tx < ntx; ++tx) {
-            for (uint64_t il = 0; il < n_loc; ++il) {
-                Ray *r = &w->cur_rays[tx * n_loc + il];
-                r->o = tx_pos[tx];
-                memcpy(&r->d, dsrc + 3 * il, sizeof(Vec3));
-            }
-            for (uint64_t il = 0; il < n_loc; il += ch) {
-                const uint64_t len = n_loc - il < ch ? n_loc - il : ch;
-                memcpy(scat_rays->rays + tx * np + hrt_shard_global_path(&s, il), w->cur_rays + tx * n_loc + il, len * sizeof(Ray));
-            }
-        }
+        rays_ctx rc0;
+        memset(&rc0, 0, sizeof rc0);
+        rc0.s = &s; rc0.cur = w->cur_rays; rc0.dirs = dsrc; rc0.tx_pos = tx_pos; rc0.n_loc = n_loc; rc0.np = np;
+        rc0.ntx = ntx; rc0.ch = ch; rc0.n_gran = (n_loc + ch - 1) / ch;
+        rc0.dst = scat_rays->rays; rc0.dst_tx_stride = np;   /* :589: the launch block is [tx][p] */
+        hrt_parallel_ranges(rays_init_range, &rc0, n_loc, c->scatter_threads);
+        hrt_parallel_ranges(rays_copy_range, &rc0, ntx * rc0.n_gran, c->scatter_threads);
     }
-    const int can_pre = !scat_rays && !prob->tune.no_bounce_prefetch;
+    const int can_pre = !prob->tune.no_bounce_prefetch;
     /* slim records (default; HRT_FULL_RECORDS=1 copies all nine fields): see scatter_ctx */
     const int slim = !env_int("HRT_FULL_RECORDS", 0);
     static const int hs_field[4] = {HRT_HIT_OX, HRT_HIT_OY, HRT_HIT_OZ, HRT_HIT_TAU};
@@ -622,9 +673,6 @@ static int run_batch(dev_ctx *c, uint32_t g)
             DL(w->ray, hb + (uint64_t)HRT_HIT_RAY * L.cap * 4, H * 4);
             DL(w->tri, hb + (uint64_t)HRT_HIT_TRI * L.cap * 4, H * 4);
             for (int k = 0; k < 4 && slim; ++k) DL(w->hs[k], hb + (uint64_t)hs_field[k] * L.cap * 4, H * 4);
-            if (scat_rays)
-                for (int k = 0; k < 6; ++k)
-                    DL(w->st[k], hb + (uint64_t)(HRT_HIT_OX + k) * L.cap * 4, H * 4);
         }
         /* Q10: the reference adds dot(d - d, mesh_velocity) * f/c -- a signed zero, or NaN for a
          * non-finite velocity -- to freq_shift[tx*np + path] of every ray that hit (:663-664),
@@ -695,6 +743,18 @@ static int run_batch(dev_ctx *c, uint32_t g)
                 if (flip & 1) FETCH_RX(b, rx, w->rec2, w->mask2, r0, r1);
                 else FETCH_RX(b, rx, w->rec, w->mask, r0, r1);
             }
+            /* RaysInfo: the hits' new origins and directions, wanted behind the last block.  Requested behind block
+             * 0's sync, so that they travel while block 0 is scattered and block 1's sync waits for them -- with a
+             * single block in front of its sync */
+#define FETCH_ST()                                                                                   \
+    do {                                                                                             \
+        int e_ = 0;                                                                                  \
+        for (int q = 0; q < 6 && !e_; ++q)                                                           \
+            e_ = hrt_hip_d2h_async(w->st[q], (const uint8_t *)w->d_ws + hb + (uint64_t)(HRT_HIT_OX + q) * L.cap * 4, H * 4, \
+                                   (q & 1) ? w->copy_stream2 : w->copy_stream);                      \
+        if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }       \
+    } while (0)
+            if (k == 0 && scat_rays && nblk == 1) FETCH_ST();
             const size_t slot = (size_t)k + (size_t)flip;
             float *const *cur_rec = (slot & 1) ? w->rec2 : w->rec;
             const uint64_t *cur_mask = (slot & 1) ? w->mask2 : w->mask;
@@ -703,6 +763,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
                 if (!e) e = hrt_hip_stream_sync(w->copy_stream2);
                 if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
             }
+            if (k == 0 && scat_rays && nblk > 1) FETCH_ST();
             if (k + 1 < nblk) {
                 if (slot & 1) FETCH_RX(b, BLK_RX(k + 1), w->rec, w->mask, BLK_I0(k + 1), BLK_I1(k + 1));
                 else FETCH_RX(b, BLK_RX(k + 1), w->rec2, w->mask2, BLK_I0(k + 1), BLK_I1(k + 1));
@@ -742,6 +803,7 @@ static int run_batch(dev_ctx *c, uint32_t g)
 #undef BLK_RX
 #undef BLK_I0
 #undef BLK_I1
+#undef FETCH_ST
 #undef FETCH_RX
 
         /* ---- RaysInfo snapshots (:732-743), this batch's paths.  The state of a ray after bounce b goes
@@ -750,30 +812,17 @@ static int run_batch(dev_ctx *c, uint32_t g)
          * (granule by granule), on whatever device it ran.  The active bits go into the shared per-bounce
          * bit strings; the reference's copies of them (Q12) are made once all batches are done. ---- */
         if (scat_rays) {
-            uint8_t *act = c->act_all + (b + 1) * (nq / 8 + 1);
             const uint32_t ch = s.chunk ? s.chunk : 4096u;
-            for (uint64_t i = 0; i < H; ++i) {
-                const uint32_t ql = w->ray[i];           /* tx * n_loc + local path */
-                const uint64_t tx = ql / n_loc, il = ql - tx * n_loc;
-                const uint64_t p = hrt_shard_global_path(&s, il);
-                const uint64_t q = tx * np + p;
-                /* bytes shared with another batch's paths (a TX boundary that is not a multiple of 8, the
-                 * ends of a granule) are updated atomically; the rest of a granule's bytes are this batch's */
-                const uint64_t g0 = tx * np + p / ch * ch, g1 = tx * np + (p / ch * ch + ch < np ? p / ch * ch + ch : np);
-                const uint8_t bit = (uint8_t)(1u << (q % 8));
-                if (q / 8 > g0 / 8 && q / 8 < (g1 - 1) / 8) act[q / 8] |= bit;
-                else __atomic_fetch_or(&act[q / 8], bit, __ATOMIC_RELAXED);
-                Ray *r = &w->cur_rays[ql];
-                r->o = (Vec3){w->st[0][i], w->st[1][i], w->st[2][i]};
-                r->d = (Vec3){w->st[3][i], w->st[4][i], w->st[5][i]};
-            }
-            for (size_t tx = 0; tx < ntx; ++tx) {
-                Ray *dst = scat_rays->rays + (tx * nb + (b + 1)) * np;
-                for (uint64_t il = 0; il < n_loc; il += ch) {
-                    const uint64_t len = n_loc - il < ch ? n_loc - il : ch;
-                    memcpy(dst + hrt_shard_global_path(&s, il), w->cur_rays + tx * n_loc + il, len * sizeof(Ray));
-                }
-            }
+            rays_ctx rcb;
+            memset(&rcb, 0, sizeof rcb);
+            rcb.s = &s; rcb.cur = w->cur_rays; rcb.ray = w->ray; rcb.st = w->st; rcb.n_loc = n_loc; rcb.np = np;
+            rcb.ntx = ntx; rcb.ch = ch; rcb.n_gran = (n_loc + ch - 1) / ch;
+            rcb.act = c->act_all + (b + 1) * (nq / 8 + 1);
+            rcb.dst = scat_rays->rays + (b + 1) * np; rcb.dst_tx_stride = nb * np;   /* slot (tx * nb + b + 1) * np + p */
+            /* (the st arrays were requested with the first block and every later block's sync waited for them; the
+             * next bounce's arrays may be on their way behind them: not waited for here) */
+            hrt_parallel_ranges(rays_update_range, &rcb, H, c->scatter_threads);
+            hrt_parallel_ranges(rays_copy_range, &rcb, ntx * rcb.n_gran, c->scatter_threads);
         }
     }
     c->t_rb += hrt_now_s() - t0;
