@@ -208,12 +208,20 @@ class Tracer:
         t = self.ws[off:off + n * 4]
         return t.view(dtype)
 
-    def counts(self):
+    def counts(self, retrace=True):
+        """counts[0 .. nb + 1] of the last step (counts[b + 1] = hits of bounce b).  A VOID step -- a fused launch or
+        the chain kernel gave up waiting because the GPU is shared (HRT_ERR_FUSE_TIMEOUT / HRT_ERR_CHAIN_TIMEOUT in
+        the error word; the library has switched that kernel off for the process by the time this is read) -- is
+        traced again here, like the drop-in calls do (retrace=False: raise instead)."""
         torch = self.torch
-        c = self._view(int(self.layout.off_counts), self.nb + 2, torch.int32).cpu().numpy()
-        c = c.astype(np.int64) & 0xFFFFFFFF
-        c[0] = self.ntx * self.num_local
-        if int(c[self.nb + 1]) & 0x300:   # HRT_ERR_FUSE_TIMEOUT | HRT_ERR_CHAIN_TIMEOUT (hrt_kparams.h)
+        for attempt in range(3):
+            c = self._view(int(self.layout.off_counts), self.nb + 2, torch.int32).cpu().numpy()
+            c = c.astype(np.int64) & 0xFFFFFFFF
+            c[0] = self.ntx * self.num_local
+            if not (int(c[self.nb + 1]) & 0x300) or not retrace or attempt == 2:   # (hrt_kparams.h: HRT_ERR_VOID)
+                break
+            self.trace()
+        if int(c[self.nb + 1]) & 0x300:
             raise _lib.HrtError("a fused launch timed out waiting for the workgroups in front of it (the GPU is shared "
                                 "with other such kernels): this step is void -- trace() again; the library has switched "
                                 "to smaller kernels for the rest of the process")
