@@ -271,22 +271,35 @@ def main():
         f32p = ctypes.POINTER(ctypes.c_float)
         _l.check(_l.load().hrt_selftest_math(local_rank, 1, x.ctypes.data_as(f32p), y.ctypes.data_as(f32p), n))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t_all = xreduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
-    dt = float(t_all.item())
+    # A VOID step (a fused launch / the chain kernel gave up waiting: the GPU is shared with other such kernels; the
+    # library then switches that kernel off and callers trace again) must not be timed as if it were work: the error
+    # word is looked at behind the region, on every rank, and the region is timed again on the smaller kernels.
+    void_retimed = 0
+    from hermespy_rt_amd import lib as _libm
+    for attempt in range(3):
+        fb0 = int(_libm.load().hrt_fallback_state())
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t_all = xreduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
+        dt = float(t_all.item())
+        # (a void step anywhere in the region: the last step's error word, or a kernel switched off meanwhile)
+        void = 1.0 if ((tr.error_word() & 0x300) or int(_libm.load().hrt_fallback_state()) != fb0) else 0.0
+        void = float(xreduce(torch.tensor([void], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
+        if not void:
+            break
+        void_retimed += 1
     # per-kernel HIP events (one hrt_timer = the events of one step, recorded on the launch stream,
     # read afterwards): a SEPARATE untimed pass right after the timed region, every step of it
     # instrumented -- the timed steps carry no events (they cost ~4 % of a 1.6 ms step)
@@ -437,6 +450,10 @@ def main():
             nonzero_paths_per_sec=(unblk + nrx * ntx) * args.steps / dt,
             work=dict(live=live, records=records, records_unblocked=unblk, tests=tests),
             roofline=roofline)
+        # kernels this process switched off after a timeout (0: none; bit 0 fused launches, bit 1 the chain kernel:
+        # the GPU was shared) and how often the timed region was timed again because a step in it was void
+        out["fallback_state"] = int(_libm.load().hrt_fallback_state())
+        out["void_regions_retimed"] = void_retimed
         if kstats:
             out["kernel_stats_all_steps"] = dict(columns=["wave_traces", "usable_packets", "candidates", "stage2", "stage3", "exact", "c6", "c7"], primary0=kstats[0], primary=kstats[1], shadow=kstats[2])
 

@@ -1145,6 +1145,8 @@ void hrt_fuse_disable(void) { g_fuse_off = 1; }
 int hrt_fuse_disabled(void) { return g_fuse_off; }
 void hrt_chain_disable(void) { g_chain_off = 1; }
 int hrt_chain_disabled(void) { return g_chain_off; }
+/* which kernels this process has switched off after a timeout (bit 0: fused launches, bit 1: the chain kernel) */
+int hrt_fallback_state(void) { return (g_fuse_off ? 1 : 0) | (g_chain_off ? 2 : 0); }
 /* what the host does about a void step (error word of its counts): 1 = run it again (something was switched off) */
 int hrt_void_step_retry(uint32_t err_word)
 {

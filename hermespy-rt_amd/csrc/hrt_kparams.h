@@ -10,11 +10,13 @@ extern "C" {
 #endif
 
 #define HRT_NO_HIT 0xFFFFFFFFu
+#ifndef HRT_ERR_FUSE_TIMEOUT          /* (public: include/hrt_device.h carries the same three values) */
 #define HRT_ERR_FUSE_TIMEOUT 0x100u   /* error word of a trace (counts[nb + 1]): a fused launch timed out waiting for its
                                        * prefix (GPU shared with other fused kernels); the step is void, redo it unfused */
 #define HRT_ERR_CHAIN_TIMEOUT 0x200u  /* ... the kernel that runs launches 1 .. nb as one (hrt_chain_kernel) found its grid not
                                        * resident, or timed out in a grid barrier; the step is void, redo it launch by launch */
 #define HRT_ERR_VOID (HRT_ERR_FUSE_TIMEOUT | HRT_ERR_CHAIN_TIMEOUT)
+#endif
 #define HRT_NUM_MATERIALS 17
 #define HRT_TRI_FLOATS 20  /* v1(3) e1(3) e2(3) n(3) E_d c_uv c_w (culling tolerances) |e1| |e2| |e2-e1| |e1xe2| mesh_id(u32) */
 #define HRT_MAT_FLOATS 16  /* 12 MaterialPrecomputed fields, s, s1_alpha, pad(2) */

@@ -208,6 +208,10 @@ class Tracer:
         t = self.ws[off:off + n * 4]
         return t.view(dtype)
 
+    def error_word(self):
+        """counts[nb + 1] of the last step: 0, or HRT_ERR_* bits (0x100 / 0x200: the step is void, hrt_kparams.h)"""
+        return int(self._view(int(self.layout.off_counts), self.nb + 2, self.torch.int32)[self.nb + 1].item()) & 0xFFFFFFFF
+
     def counts(self, retrace=True):
         """counts[0 .. nb + 1] of the last step (counts[b + 1] = hits of bounce b).  A VOID step -- a fused launch or
         the chain kernel gave up waiting because the GPU is shared (HRT_ERR_FUSE_TIMEOUT / HRT_ERR_CHAIN_TIMEOUT in

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libhermespy_rt_amd.so")
 EXPORTED = (
     "compute_paths", "scene_load", "scene_save", "hrt_compute_paths_ex", "hrt_compute_paths_interleaved",
     "hrt_compute_paths_list", "hrt_path_list_free", "hrt_last_error",
-    "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_problem_num_triangles",
+    "hrt_version", "hrt_cache_clear", "hrt_problem_create", "hrt_problem_destroy", "hrt_fallback_state", "hrt_problem_num_triangles",
     "hrt_problem_num_rx", "hrt_problem_num_tx", "hrt_problem_device", "hrt_problem_eta_table",
     "hrt_problem_normals", "hrt_problem_tri_ids", "hrt_problem_tri_order", "hrt_shard_num_local",
     "hrt_shard_global_path", "hrt_launch_dirs_host", "hrt_launch_order_host", "hrt_launch_dirs_device", "hrt_launch_order_device", "hrt_layout_query", "hrt_trace",
@@ -118,6 +118,8 @@ def load():
                                      C.c_size_t, C.c_int, C.POINTER(vp)]
     L.hrt_problem_destroy.argtypes = [vp]
     L.hrt_problem_destroy.restype = None
+    L.hrt_fallback_state.argtypes = []
+    L.hrt_fallback_state.restype = C.c_int
     for n in ("hrt_problem_num_triangles", "hrt_problem_num_rx", "hrt_problem_num_tx"):
         getattr(L, n).argtypes = [vp]
         getattr(L, n).restype = u32

@@ -35,6 +35,16 @@ int hrt_problem_create(const Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_po
                        const Vec3 *rx_vel, const Vec3 *tx_vel, float carrier_frequency_GHz,
                        size_t num_rx, size_t num_tx, int device, hrt_problem **out);
 void hrt_problem_destroy(hrt_problem *p);
+/* Fused launches and the chain kernel wait for each other's workgroups; when a wait runs out (the GPU is shared
+ * with other such kernels) the step is void (HRT_ERR_FUSE_TIMEOUT / HRT_ERR_CHAIN_TIMEOUT in counts[nb + 1]), the
+ * library switches that kernel off for the rest of the process and callers trace again (the drop-in calls do so
+ * themselves).  hrt_fallback_state: bit 0 = fused launches are off, bit 1 = the chain kernel is off. */
+int hrt_fallback_state(void);
+#ifndef HRT_ERR_FUSE_TIMEOUT   /* (the same values in csrc/hrt_kparams.h, for the kernels) */
+#define HRT_ERR_FUSE_TIMEOUT 0x100u
+#define HRT_ERR_CHAIN_TIMEOUT 0x200u
+#define HRT_ERR_VOID (HRT_ERR_FUSE_TIMEOUT | HRT_ERR_CHAIN_TIMEOUT)
+#endif
 uint32_t hrt_problem_num_triangles(const hrt_problem *p);
 uint32_t hrt_problem_num_rx(const hrt_problem *p);
 uint32_t hrt_problem_num_tx(const hrt_problem *p);
