@@ -62,6 +62,7 @@ void hrt_cache_clear(void)
     g_cache.np = 0; g_cache.dirs = NULL; g_cache.order = NULL;
     pthread_mutex_unlock(&g_cache_lock);
     pool_release_all();
+    hrt_list_cache_clear();   /* (path_list.c) */
     hrt_parallel_release();   /* ... and the calling thread's parked helper threads */
 }
 

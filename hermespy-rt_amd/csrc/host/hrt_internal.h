@@ -128,6 +128,7 @@ int hrt_void_step_retry(uint32_t err_word);
 #define HRT_POOL_MAX_DEFAULT (5ull << 30)   /* HRT_POOL_MAX_BYTES: what a worker may keep between calls */
 uint64_t hrt_worker_held_bytes(uint64_t ws_bytes, uint64_t dirs_rows, uint64_t cap);
 int hrt_batch_fits_pool(uint64_t ws_bytes, uint64_t dirs_rows, uint64_t cap);
+void hrt_list_cache_clear(void);   /* path_list.c: the blocks kept from the last freed path list */
 
 /* ---- buffers of one device worker of the drop-in calls (compute_paths.c), pooled between calls ---- */
 typedef struct {

@@ -9,6 +9,8 @@
  * device-resident API (include/hrt_device.h) only.
  */
 #define _GNU_SOURCE
+#include <malloc.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -21,12 +23,67 @@ static uint64_t pl_env_u64(const char *name, uint64_t dflt)
     return (v && *v) ? (uint64_t)strtoull(v, NULL, 10) : dflt;
 }
 
+/* The blocks of the last freed list are kept for the next one (one set, at most HRT_LIST_KEEP_MAX bytes;
+ * hrt_cache_clear() releases them, HRT_NO_CACHE=1 disables): a list is written once, front to back, and on fresh
+ * memory most of that time is page faults -- 1.5 GB for C3's 23 M records. */
+#define HRT_LIST_BLOCKS 14
+#define HRT_LIST_KEEP_MAX (4ull << 30)
+static pthread_mutex_t g_list_lock = PTHREAD_MUTEX_INITIALIZER;
+static void *g_list_blk[HRT_LIST_BLOCKS];      /* in the order of list_blocks() */
+static size_t g_list_bytes[HRT_LIST_BLOCKS];
+
+static void list_blocks(hrt_path_list *pl, void ***b)
+{
+    b[0] = (void **)&pl->rx; b[1] = (void **)&pl->tx; b[2] = (void **)&pl->bounce; b[3] = (void **)&pl->path;
+    b[4] = (void **)&pl->a_te_re; b[5] = (void **)&pl->a_te_im; b[6] = (void **)&pl->a_tm_re; b[7] = (void **)&pl->a_tm_im;
+    b[8] = (void **)&pl->tau; b[9] = (void **)&pl->direction_rx; b[10] = (void **)&pl->freq_shift;
+    b[11] = (void **)&pl->unblocked; b[12] = (void **)&pl->mesh; b[13] = (void **)&pl->face;
+}
+
+void hrt_list_cache_clear(void)
+{
+    pthread_mutex_lock(&g_list_lock);
+    for (int k = 0; k < HRT_LIST_BLOCKS; ++k) { free(g_list_blk[k]); g_list_blk[k] = NULL; g_list_bytes[k] = 0; }
+    pthread_mutex_unlock(&g_list_lock);
+}
+
+/* a kept block of field k with at least `bytes`, or NULL */
+static void *list_cache_take(int k, size_t bytes, size_t *got)
+{
+    void *p = NULL;
+    pthread_mutex_lock(&g_list_lock);
+    if (g_list_blk[k] && g_list_bytes[k] >= bytes) {
+        p = g_list_blk[k]; *got = g_list_bytes[k];
+        g_list_blk[k] = NULL; g_list_bytes[k] = 0;
+    }
+    pthread_mutex_unlock(&g_list_lock);
+    return p;
+}
+
 void hrt_path_list_free(hrt_path_list *pl)
 {
     if (!pl) return;
-    free(pl->rx); free(pl->tx); free(pl->bounce); free(pl->path);
-    free(pl->a_te_re); free(pl->a_te_im); free(pl->a_tm_re); free(pl->a_tm_im); free(pl->tau);
-    free(pl->direction_rx); free(pl->freq_shift); free(pl->unblocked); free(pl->mesh); free(pl->face);
+    void **b[HRT_LIST_BLOCKS];
+    list_blocks(pl, b);
+    const char *nc = getenv("HRT_NO_CACHE");
+    int keep = !(nc && *nc && *nc != '0') && pl->rx != NULL;
+    size_t bytes[HRT_LIST_BLOCKS], total = 0;
+    for (int k = 0; k < HRT_LIST_BLOCKS && keep; ++k) {
+        bytes[k] = *b[k] ? malloc_usable_size(*b[k]) : 0;
+        total += bytes[k];
+        if (!*b[k]) keep = 0;
+    }
+    if (keep && total <= HRT_LIST_KEEP_MAX) {
+        pthread_mutex_lock(&g_list_lock);
+        for (int k = 0; k < HRT_LIST_BLOCKS; ++k) {
+            if (g_list_bytes[k] >= bytes[k]) { free(*b[k]); continue; }   /* the kept one is at least as big */
+            free(g_list_blk[k]);
+            g_list_blk[k] = *b[k]; g_list_bytes[k] = bytes[k];
+        }
+        pthread_mutex_unlock(&g_list_lock);
+    } else {
+        for (int k = 0; k < HRT_LIST_BLOCKS; ++k) free(*b[k]);
+    }
     free(pl->los);
     memset(pl, 0, sizeof *pl);
 }
@@ -42,16 +99,21 @@ static int pl_reserve(hrt_path_list *pl, uint64_t *cap, uint64_t need)
 #define GROW(field, type)                                                        \
     do {                                                                         \
         void *q_ = NULL;                                                         \
+        size_t got_ = 0;                                                         \
         const size_t bytes_ = (((size_t)nc * sizeof(type)) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); \
-        if (posix_memalign(&q_, (size_t)2 << 20, bytes_) != 0 || !q_)           \
-            return hrt_fail(HRT_E_NOMEM, "out of host memory");                  \
-        (void)madvise(q_, bytes_, MADV_HUGEPAGE);                                \
+        q_ = list_cache_take(blk_++, bytes_, &got_);   /* (a block kept from the last list: already paged in) */ \
+        if (!q_) {                                                               \
+            if (posix_memalign(&q_, (size_t)2 << 20, bytes_) != 0 || !q_)       \
+                return hrt_fail(HRT_E_NOMEM, "out of host memory");              \
+            (void)madvise(q_, bytes_, MADV_HUGEPAGE);                            \
+        }                                                                        \
         if (pl->field) {                                                         \
             memcpy(q_, pl->field, (size_t)pl->num * sizeof(type));               \
             free(pl->field);                                                     \
         }                                                                        \
         pl->field = (type *)q_;                                                  \
     } while (0)
+    int blk_ = 0;   /* (the order of list_blocks()) */
     GROW(rx, uint32_t); GROW(tx, uint32_t); GROW(bounce, uint32_t); GROW(path, uint64_t);
     GROW(a_te_re, float); GROW(a_te_im, float); GROW(a_tm_re, float); GROW(a_tm_im, float);
     GROW(tau, float); GROW(direction_rx, Vec3); GROW(freq_shift, float); GROW(unblocked, uint8_t);
@@ -253,10 +315,16 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
             st.tests += bs.tests - (g ? (uint64_t)nrx * ntx * prob->num_tri : 0);
         }
         if (g == 0) DLP(out->los, L.off_los, nrx * ntx * HRT_LOS_FLOATS * sizeof(float));
-        {   /* room for every record of this batch (exact with include_blocked, <= 1.2x otherwise) */
+        {   /* room for every record of this batch (exact with include_blocked, <= 1.2x otherwise).  With several
+             * batches the first one sizes the whole list: the batches are round-robin shards of one launch set, so
+             * each holds 1 / G of the records within a fraction of a percent -- growing the list batch by batch
+             * copied it G times (C5, 16 batches, 45 GB of list: 12 s of the call) */
             uint64_t recs = 0;
             for (size_t b = 0; b < nb; ++b) recs += (uint64_t)nrx * h_counts[b + 1];
-            if ((rc = pl_reserve(out, &cap_out, out->num + recs))) goto done;
+            uint64_t want = out->num + recs;
+            if (g == 0 && G > 1) want = recs * G + recs * G / 32 + 65536;
+            if (want < out->num + recs) want = out->num + recs;
+            if ((rc = pl_reserve(out, &cap_out, want))) goto done;
         }
         int pre = 0, flip = 0;   /* staging set of a block: (rx + flip) & 1 */
         const int can_pre = !prob->tune.no_bounce_prefetch;
@@ -344,6 +412,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
 #undef FETCH_PL
 #undef FETCH_HITS
 #undef DLP
+    st.num_batches = G;
     st.t_launch_dirs_s = t_dirs;
     st.t_device_s = t_dev;
     st.t_readback_s = t_rb;

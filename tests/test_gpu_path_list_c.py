@@ -69,3 +69,31 @@ def test_more_host_threads_than_the_writers_have_slots(product_lib, monkeypatch)
     d16 = abi.run_compute_paths(product_lib, *K.args(K.small(K.C3, 600000)), with_rays=False)
     for k in ("a_te_re", "tau", "freq_shift"):
         assert np.array_equal(d64["scat"][k].view(np.uint32), d16["scat"][k].view(np.uint32)), k
+
+
+def test_list_of_several_batches_and_reused_blocks(product_lib, monkeypatch):
+    """The list of a call that runs as several batches (its size comes from the first batch, it must not be
+    short) equals the one-batch list as a set of records; and a list written into the blocks kept from the
+    last freed one (hrt_path_list_free keeps one set) carries nothing of the old list."""
+    c = K.small(K.C4_DOPPLER, 300000)
+    one = abi.run_compute_paths_list(product_lib, *K.args(c), include_blocked=True)
+    small = abi.run_compute_paths_list(product_lib, *K.args(K.small(K.C2, 20000)), include_blocked=True)   # into kept blocks
+    assert small["rx"].size > 0
+    monkeypatch.setenv("HRT_WORKSPACE_BYTES", str(60 << 20))
+    st = lib.Stats()
+    many = abi.run_compute_paths_list(product_lib, *K.args(c), include_blocked=True, stats=st)
+    assert int(st.num_batches) >= 4
+    assert many["rx"].size == one["rx"].size
+
+    def key(P):
+        k = ((P["rx"].astype(np.int64) * 4 + P["tx"]) * 64 + P["bounce"]) * (1 << 32) + P["path"].astype(np.int64)
+        return np.argsort(k, kind="stable"), k
+    oa, ka = key(one)
+    ob, kb = key(many)
+    assert np.array_equal(ka[oa], kb[ob])
+    for f in ("a_te_re", "a_te_im", "a_tm_re", "a_tm_im", "tau", "unblocked", "mesh", "face"):
+        assert np.array_equal(one[f][oa].view(np.uint8), many[f][ob].view(np.uint8)), f
+    # (a blocked record has no direction and no Doppler term: the reference does not write those slots, Q2)
+    ub = one["unblocked"][oa].astype(bool)
+    assert np.array_equal(one["direction_rx"][oa][ub].view(np.uint32), many["direction_rx"][ob][ub].view(np.uint32))
+    assert np.array_equal(one["freq_shift"][oa][ub].view(np.uint32), many["freq_shift"][ob][ub].view(np.uint32))
