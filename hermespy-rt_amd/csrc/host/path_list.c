@@ -10,12 +10,23 @@
  */
 #define _GNU_SOURCE
 #include <malloc.h>
+#include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 
 #include "hrt_internal.h"
+
+/* (the slim path forms tau and direction_rx here: nothing in this file may be contracted into an FMA) */
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT OFF
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+#if defined(__FAST_MATH__)
+#error "path_list.c must not be built with -ffast-math"
+#endif
 
 static uint64_t pl_env_u64(const char *name, uint64_t dflt)
 {
@@ -135,6 +146,11 @@ typedef struct {
     uint64_t n_loc, base;
     uint32_t rx, bounce;
     int include_blocked;
+    /* slim records (default, as in compute_paths.c: HRT_FULL_RECORDS=1 copies all nine fields): tau and
+     * direction_rx are not copied (16 of a record's 36 bytes) but formed here from the hit's origin and delay
+     * (16 bytes per HIT) with the reference's float sequence (src/compute_paths.c:676-678, :707-709) */
+    const float *hs[4];   /* o.x o.y o.z tau of the hits; NULL: the records carry the fields */
+    float rxp[3];
     uint64_t start[HRT_MAX_SCATTER_THREADS + 1];   /* first output entry of every range */
     uint64_t i0[HRT_MAX_SCATTER_THREADS], i1[HRT_MAX_SCATTER_THREADS];
 } fill_ctx;
@@ -166,9 +182,22 @@ static void fill_one(fill_ctx *c, int tid)
         out->a_te_im[n] = c->field[HRT_REC_A_TE_IM][i];
         out->a_tm_re[n] = c->field[HRT_REC_A_TM_RE][i];
         out->a_tm_im[n] = c->field[HRT_REC_A_TM_IM][i];
-        out->tau[n] = c->field[HRT_REC_TAU][i];
-        out->direction_rx[n] = (Vec3){c->field[HRT_REC_DIRX][i], c->field[HRT_REC_DIRY][i],
-                                      c->field[HRT_REC_DIRZ][i]};
+        if (c->hs[0]) {
+            if (ub) {
+                const float wx = c->rxp[0] - c->hs[0][i], wy = c->rxp[1] - c->hs[1][i], wz = c->rxp[2] - c->hs[2][i];
+                const float d2rx = sqrtf((wx * wx + wy * wy) + wz * wz);
+                const float ux = wx / d2rx, uy = wy / d2rx, uz = wz / d2rx;
+                out->tau[n] = c->hs[3][i] + d2rx / HRT_C_F;
+                out->direction_rx[n] = (Vec3){-ux, -uy, -uz};
+            } else {
+                out->tau[n] = 0.f;   /* :688 */
+                out->direction_rx[n] = (Vec3){0.f, 0.f, 0.f};   /* (not written by the reference: Q2) */
+            }
+        } else {
+            out->tau[n] = c->field[HRT_REC_TAU][i];
+            out->direction_rx[n] = (Vec3){c->field[HRT_REC_DIRX][i], c->field[HRT_REC_DIRY][i],
+                                          c->field[HRT_REC_DIRZ][i]};
+        }
         out->freq_shift[n] = c->fs0[i] - c->field[HRT_REC_DFS][i];
         out->unblocked[n] = (uint8_t)ub;
         out->mesh[n] = c->prob->h_tri_mesh[c->tri[i]];
@@ -211,9 +240,11 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
     void *d_ws = NULL, *d_dirs = NULL, *d_order = NULL;
     float *h_dirs = NULL, **h_field = NULL, **h_field2 = NULL, *h_fs0 = NULL, *h_fs02 = NULL;
     uint64_t *h_mask = NULL, *h_mask2 = NULL;
-    void *copy_stream = NULL;
+    void *copy_stream = NULL, *copy_stream2 = NULL;
     const int host_launch = (int)pl_env_u64("HRT_HOST_LAUNCH", 0);
     uint32_t *h_order = NULL, *h_ray = NULL, *h_tri = NULL, *h_ray2 = NULL, *h_tri2 = NULL, *h_counts = NULL;
+    float *h_hs[4] = {NULL, NULL, NULL, NULL}, *h_hs2[4] = {NULL, NULL, NULL, NULL};
+    int slim = 0;
     uint64_t cap_out = 0;
     const int threads = hrt_host_threads();
     double t_dev = 0.0, t_rb = 0.0, t_dirs = 0.0;
@@ -254,7 +285,10 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         h_ray = wc.w.ray; h_tri = wc.w.tri; h_fs0 = wc.w.fs0;
         h_ray2 = wc.w.ray2; h_tri2 = wc.w.tri2; h_fs02 = wc.w.fs02;
         h_field = wc.w.rec; h_field2 = wc.w.rec2; h_mask = wc.w.mask; h_mask2 = wc.w.mask2;
+        slim = wc.w.hs[0] != NULL && wc.w.hs2[0] != NULL;   /* (allocated unless HRT_FULL_RECORDS=1) */
+        for (int k = 0; k < 4; ++k) { h_hs[k] = wc.w.hs[k]; h_hs2[k] = wc.w.hs2[k]; }
         copy_stream = wc.w.copy_stream;
+        copy_stream2 = wc.w.copy_stream2;
         if (host_launch) {
             h_dirs = (float *)malloc(hrt_shard_num_local(&(hrt_shard){np, 0, G, 0, (uint32_t)nb}) * 12);
             if (!h_dirs) { rc = hrt_fail(HRT_E_NOMEM, "out of host memory"); goto done; }
@@ -335,12 +369,16 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
              * stream, a block ahead of the one being written into the list; the NEXT bounce's per-hit data
              * and first block are requested during the last block of this one (`pre`), into the second
              * pair of arrays / the other staging set. */
-#define FETCH_HITS(B, HN, RAY, TRI, FS0)                                                          \
+#define FETCH_HITS(B, HN, RAY, TRI, FS0, HS)                                                      \
     do {                                                                                          \
+        static const int hs_field_[4] = {HRT_HIT_OX, HRT_HIT_OY, HRT_HIT_OZ, HRT_HIT_TAU};        \
         const uint64_t hb_ = L.off_hits + (uint64_t)(B) * L.hit_block_bytes;                      \
         int e_ = hrt_hip_d2h_async((RAY), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_RAY * L.cap * 4, (HN) * 4, copy_stream); \
-        if (!e_) e_ = hrt_hip_d2h_async((TRI), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_TRI * L.cap * 4, (HN) * 4, copy_stream); \
+        if (!e_) e_ = hrt_hip_d2h_async((TRI), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_TRI * L.cap * 4, (HN) * 4, copy_stream2); \
         if (!e_) e_ = hrt_hip_d2h_async((FS0), (const uint8_t *)d_ws + hb_ + (uint64_t)HRT_HIT_FS0 * L.cap * 4, (HN) * 4, copy_stream); \
+        for (int q_ = 0; q_ < 4 && slim && !e_; ++q_)                                             \
+            e_ = hrt_hip_d2h_async((HS)[q_], (const uint8_t *)d_ws + hb_ + (uint64_t)hs_field_[q_] * L.cap * 4, (HN) * 4, \
+                                   (q_ & 1) ? copy_stream : copy_stream2);                        \
         if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }    \
     } while (0)
 #define FETCH_PL(B, HN, RX, SET, MASK)                                                            \
@@ -348,7 +386,9 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
         const uint64_t rb_ = L.off_recs + (uint64_t)(B) * L.rec_block_bytes + (uint64_t)(RX) * HRT_REC_FIELDS * L.cap * 4; \
         int e_ = 0;                                                                               \
         for (int k = 0; k < HRT_REC_FIELDS && !e_; ++k)                                           \
-            e_ = hrt_hip_d2h_async((SET)[k], (const uint8_t *)d_ws + rb_ + (uint64_t)k * L.cap * 4, (HN) * 4, copy_stream); \
+            if (!(slim && k >= HRT_REC_TAU && k <= HRT_REC_DIRZ))   /* formed on the host from the hits */ \
+            e_ = hrt_hip_d2h_async((SET)[k], (const uint8_t *)d_ws + rb_ + (uint64_t)k * L.cap * 4, (HN) * 4,         \
+                                   (k & 1) ? copy_stream2 : copy_stream);                         \
         if (!e_) e_ = hrt_hip_d2h_async((MASK), (const uint8_t *)d_ws + L.off_masks + ((uint64_t)(B) * nrx + (RX)) * (L.cap / 64) * 8, \
                                         ((HN) + 63) / 64 * 8, copy_stream);                       \
         if (e_) { rc = hrt_fail(HRT_E_HIP, "hipMemcpyAsync D2H failed (%d)", e_); goto done; }    \
@@ -357,9 +397,10 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                 uint32_t *t_ = h_ray; h_ray = h_ray2; h_ray2 = t_;
                 t_ = h_tri; h_tri = h_tri2; h_tri2 = t_;
                 float *f_ = h_fs0; h_fs0 = h_fs02; h_fs02 = f_;
+                for (int k = 0; k < 4; ++k) { f_ = h_hs[k]; h_hs[k] = h_hs2[k]; h_hs2[k] = f_; }
                 pre = 0;
             } else {
-                FETCH_HITS(b, H, h_ray, h_tri, h_fs0);
+                FETCH_HITS(b, H, h_ray, h_tri, h_fs0, h_hs);
                 if (flip & 1) FETCH_PL(b, H, 0, h_field2, h_mask2);
                 else FETCH_PL(b, H, 0, h_field, h_mask);
             }
@@ -368,7 +409,8 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                 float *const *cur_field = (slot & 1) ? h_field2 : h_field;
                 const uint64_t *cur_mask = (slot & 1) ? h_mask2 : h_mask;
                 {
-                    const int e = hrt_hip_stream_sync(copy_stream);   /* block rx has landed */
+                    int e = hrt_hip_stream_sync(copy_stream);   /* block rx has landed */
+                    if (!e) e = hrt_hip_stream_sync(copy_stream2);
                     if (e) { rc = hrt_fail(HRT_E_HIP, "hipStreamSynchronize failed (%d)", e); goto done; }
                 }
                 if (rx + 1 < nrx) {   /* the copy of the next block runs while this one is written out */
@@ -376,7 +418,7 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                     else FETCH_PL(b, H, rx + 1, h_field2, h_mask2);
                 } else if (can_pre && b + 1 < nb && h_counts[b + 2] != 0) {   /* ... or the start of the next bounce */
                     const uint64_t Hn = h_counts[b + 2];
-                    FETCH_HITS(b + 1, Hn, h_ray2, h_tri2, h_fs02);
+                    FETCH_HITS(b + 1, Hn, h_ray2, h_tri2, h_fs02, h_hs2);
                     if (slot & 1) FETCH_PL(b + 1, Hn, 0, h_field, h_mask);
                     else FETCH_PL(b + 1, Hn, 0, h_field2, h_mask2);
                     pre = 1;
@@ -388,6 +430,10 @@ int hrt_compute_paths_list(Scene *scene, const Vec3 *rx_pos, const Vec3 *tx_pos,
                     fc.out = out; fc.s = &s; fc.prob = prob; fc.ray = h_ray; fc.tri = h_tri; fc.fs0 = h_fs0;
                     fc.field = cur_field; fc.mask = cur_mask; fc.n_loc = n_loc; fc.base = out->num;
                     fc.rx = (uint32_t)rx; fc.bounce = (uint32_t)b; fc.include_blocked = include_blocked;
+                    if (slim) {
+                        for (int k = 0; k < 4; ++k) fc.hs[k] = h_hs[k];
+                        fc.rxp[0] = rx_pos[rx].x; fc.rxp[1] = rx_pos[rx].y; fc.rxp[2] = rx_pos[rx].z;
+                    }
                     int nt = threads;
                     if ((uint64_t)nt > H / 65536 + 1) nt = (int)(H / 65536 + 1);
                     uint64_t total = 0, unb = 0;
@@ -424,6 +470,7 @@ done:
     if (have_buffers || wc.w.d_ws || wc.w.ray) {
         wc.rc = rc;
         if (copy_stream) hrt_hip_stream_sync(copy_stream);
+        if (copy_stream2) hrt_hip_stream_sync(copy_stream2);
         hrt_worker_release(&wc);
     }
     hrt_pool_end(pool_taken);
