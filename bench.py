@@ -523,6 +523,23 @@ def main():
                      "python_module_s = wall of hermespy_rt.compute_paths() (the pybind11 drop-in: array "
                      "allocation, the call, complex amplitudes), second and third call",
                 cold=cold, warm=warm, with_raysinfo=with_rays)
+            # ... and the same call with the result as ONE list of records (hrt_compute_paths_list):
+            # the library's own clock of the third call (the ctypes wrapper copies the list into numpy, which is
+            # not in it); skipped where those copies would not fit comfortably (C5: 45 GB of list)
+            if int(warm["records"]) * 65 <= (8 << 30):
+                try:
+                    pl_t = []
+                    for _ in range(3):
+                        st_ = _lib.Stats()
+                        pl_ = abi.run_compute_paths_list(_lib.load(), *W.args(base), stats=st_)
+                        pl_t.append(dict(t_total_s=st_.t_total_s, t_device_s=st_.t_device_s,
+                                         t_readback_and_fill_s=st_.t_readback_s, records=int(pl_["rx"].size)))
+                        del pl_
+                    out["end_to_end"]["path_list"] = dict(
+                        pl_t[-1], what="hrt_compute_paths_list: the non-zero records as one list (14 arrays, 65 B "
+                                       "per record) instead of the dense arrays; third call")
+                except Exception as e:
+                    out["end_to_end"]["path_list_error"] = repr(e)
             try:   # the Python surface HermesPy imports
                 import hermespy_rt_amd as _pkg
                 if _pkg.LIB_DIR not in sys.path:
