@@ -23,7 +23,7 @@ bit.  Round 1: configs 100-12700, soups 0-5650, big 0-660, inplane 0-3000: 0 mis
 Round 2: 90 900 more cases over every intersection mode: 0 mismatches.
 Round 3: 112 670 more (fused kernels; fine leaves forced onto every table; the wide-packet queue on, overflowing,
 absent, every packet through it; sliced LoS; logical devices; the shipped defaults): 0 mismatches.
-Round 4: 54 700 more (patch tables, records / image / chain kernels, two streams, deep soups -- `deepsoups`: 4-8 bounces
+Round 4: 89 860 more (patch tables, records / image / chain kernels, two streams, deep soups -- `deepsoups`: 4-8 bounces
 on <= 64 triangles -- and the host's block order with several TXs; six fuzzers at once on one GPU): 0 mismatches."""
 import os
 import sys
