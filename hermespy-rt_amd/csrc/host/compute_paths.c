@@ -719,8 +719,10 @@ static int run_batch(dev_ctx *c, uint32_t g)
             w->run_start[nruns] = H;
         }
         /* The blocks of this bounce in the order they are scattered.  rx 0 goes run by run, each run behind its own
-         * Q10 adds: the reference's order (tx, path, rx) on the only slots where order can be seen -- the adds touch
-         * the dense slots [0, ntx*np), which are record slots of rx 0.  Every record of rx >= 1 lives at
+         * Q10 adds: the reference's order (tx, path, rx) on the only slots where two operations meet -- the adds touch
+         * the dense slots [0, ntx*np), which are record slots of rx 0.  (A +-0 add and a subtraction commute bit for
+         * bit, tests/test_scatter_order_model.py, so even there the order could not be seen; it is kept literal: it
+         * costs ntx blocks per bounce, not ntx * nrx.)  Every record of rx >= 1 lives at
          * ((rx*ntx+tx)*nb+b)*np+p >= ntx*nb*np, beyond anything an add touches, and a record touches its own slot
          * only: rx >= 1 is scattered over the WHOLE hit list at once, nrx - 1 blocks instead of nruns * (nrx - 1)
          * (C5, 8 TX x 8 RX: 15 blocks per bounce instead of 64 -- a block costs ~0.1 ms of copies, syncs and
